@@ -1,0 +1,278 @@
+/*
+ * ptk.h -- C ABI of the MI355X (gfx950) path-tracing hot path.
+ *
+ * The reference renderer (JoarGunnarsson/Pathtracing) has no plugin or FFI seam; the
+ * boundary this library replaces is its internal C++ call boundary between the scene
+ * loader and the render/denoise loops:
+ *
+ *   raytrace_section(job, scene, buffers, ctx)        app/pathtracer.cpp:237-275
+ *   compute_pixel_color / raytrace                     app/pathtracer.cpp:39-201
+ *   find_closest_hit                                   src/objects.cpp:414-442
+ *   denoise(PixelBuffers&, vector<DenoisingTask>)      src/denoise.cpp:203-212
+ *
+ * The polymorphic Scene graph (include/scene.h:48-55) is replaced by the flat,
+ * pointer-and-size PtkSceneDesc below.  Everything is plain C: no C++ types, no torch
+ * types.  All functions return 0 on success, a negative PtkStatus on failure; the
+ * message is available from ptk_last_error() (thread local).  Nothing throws across
+ * the boundary.
+ *
+ * Random numbers.  The reference draws from three process-global sequential generators
+ * (src/utils.cpp:11-30, 120-121), which cannot be reproduced by a parallel machine.
+ * This ABI fixes a counter-based generator instead, so that any implementation (the
+ * GPU kernels, a CPU checker) produces the same numbers for the same logical draw:
+ *
+ *   mix64(z):  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9; z ^= z >> 27;
+ *              z *= 0x94D049BB133111EB; z ^= z >> 31;
+ *   key(seed, pixel, sample) = mix64(mix64(seed + G) ^ ((uint64)pixel << 32 | sample))
+ *   bits(key, n)  = mix64(key + (n + 1) * G)            G = 0x9E3779B97F4A7C15
+ *   uniform(key,n)= (bits >> 11) * 2^-53                in [0, 1)
+ *   normal        = sqrt(-2 ln(1 - u(n))) * cos(2 pi u(n+1))      consumes two counters
+ *   fork(key, n)  = mix64(key ^ mix64(n + F))           F = 0xD1B54A32D192ED03; consumes one
+ *
+ * `pixel` is the linear pixel index row*W + x, `sample` the global sample index of that
+ * pixel (job.sample_offset + i).  A path consumes counters 0,1,2,... in the order in
+ * which the reference algorithm calls its generators (AA jitter, lens, then per depth:
+ * free-flight distance, light pick, light point, eval, [visibility march on a forked
+ * key], BRDF sample, virtual-surface test, Russian roulette).  Results therefore do not
+ * depend on batch size, launch geometry or the number of GPUs.
+ */
+#ifndef PTK_H
+#define PTK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum PtkStatus {
+    PTK_OK = 0,
+    PTK_ERR_INVALID = -1,  /* bad argument / malformed scene description */
+    PTK_ERR_DEVICE = -2,   /* HIP runtime error or no usable GPU */
+    PTK_ERR_MEMORY = -3,   /* allocation failure or size over a stated limit */
+    PTK_ERR_IO = -4,       /* file missing / unreadable (host loader) */
+    PTK_ERR_FORMAT = -5    /* JSON / OBJ / .map content error (host loader) */
+} PtkStatus;
+
+/* ---- scene description -------------------------------------------------------- */
+
+/* Object subtypes of scene.json (src/scene.cpp:358-419). */
+enum { PTK_OBJ_SPHERE = 0, PTK_OBJ_PLANE = 1, PTK_OBJ_RECTANGLE = 2, PTK_OBJ_TRIANGLE = 3, PTK_OBJ_MESH = 4 };
+/* Material subtypes (src/scene.cpp:321-344). */
+enum {
+    PTK_MAT_DIFFUSE = 0,
+    PTK_MAT_REFLECTIVE = 1,
+    PTK_MAT_TRANSPARENT = 2,
+    PTK_MAT_GLOSSY = 3,
+    PTK_MAT_METALLIC_MICROFACET = 4,
+    PTK_MAT_REFLECTIVE_MICROFACET = 5,
+    PTK_MAT_TRANSPARENT_MICROFACET = 6,
+    PTK_MAT_COUNT = 7
+};
+/* Medium subtypes (src/scene.cpp:253-262). */
+enum { PTK_MEDIUM_BEERS_LAW = 0, PTK_MEDIUM_HOMOGENEOUS_SCATTERING = 1 };
+/* Camera depth-of-field modes (src/camera.cpp:39-51). */
+enum { PTK_DOF_NONE = 0, PTK_DOF_CIRCLE = 1, PTK_DOF_SQUARE = 2 };
+
+/* A ValueMap1D / ValueMap3D (include/valuemap.h): `dim` channels, row-major
+ * [height][width][dim] doubles starting at map_data[offset].  3-channel data is
+ * already converted sRGB->linear when use_gamma_correction is set, as the reference
+ * does at load time (src/scene.cpp:218-235). */
+typedef struct PtkMap {
+    int32_t width, height, dim, _pad;
+    int64_t offset;
+} PtkMap;
+
+/* include/medium.h.  Values are the raw JSON parameters; a Beer's-law medium ignores
+ * `scattering` (src/medium.cpp:37-39). */
+typedef struct PtkMedium {
+    int32_t type, _pad;
+    double scattering[3];
+    double absorption[3];
+    double emission[3];
+    double refractive_index;
+} PtkMedium;
+
+/* MaterialData (include/materials.h:41-53).  Map and medium fields are indices into
+ * the tables of the scene description, -1 when the JSON omits them (the reference
+ * then substitutes black / 0 maps and a null medium). */
+typedef struct PtkMaterial {
+    int32_t type;
+    int32_t is_light_source;
+    int32_t is_dielectric;
+    int32_t albedo_map, emission_color_map; /* 3-channel */
+    int32_t light_intensity_map, roughness_map, transparency_map; /* 1-channel */
+    int32_t internal_medium, external_medium;
+    double surface_refractive_index;
+    double extinction_coefficient;
+} PtkMaterial;
+
+/* One top-level object, in scene order.  Field use by type:
+ *   sphere     position, radius
+ *   plane      position, v1, v2                (un-normalised, as in JSON)
+ *   rectangle  position, v1, v2, L1, L2
+ *   triangle   position = p1, v1 = p2, v2 = p3
+ *   mesh       first_triangle, n_triangles into the triangle arrays; smooth shading
+ *              and UVs are per triangle (tri_flags).                               */
+typedef struct PtkObject {
+    int32_t type, material;
+    double position[3];
+    double v1[3];
+    double v2[3];
+    double L1, L2, radius;
+    int64_t first_triangle, n_triangles;
+} PtkObject;
+
+enum { PTK_TRI_SMOOTH = 1, PTK_TRI_HAS_UV = 2 };
+
+typedef struct PtkCamera {
+    double position[3];
+    double orientation_x, orientation_y, orientation_z; /* degrees, JSON "orientation" */
+    double camera_width, focal_length;
+    double aperture_size, focus_distance;
+    int32_t dof_mode, _pad;
+} PtkCamera;
+
+/* settings.json keys that affect the result (src/constants.cpp:7-19). */
+typedef struct PtkSettings {
+    int32_t width, height;
+    int32_t samples_per_pixel, samples_per_iteration;
+    int32_t max_recursion_depth, min_recursion_steps;
+    int32_t number_of_threads, use_gamma_correction;
+    int32_t bvh_leaf_size, bvh_n_axis_splits;
+    int32_t enable_next_event_estimation, enable_anti_aliasing;
+} PtkSettings;
+
+typedef struct PtkSceneDesc {
+    PtkSettings settings;
+    PtkCamera camera;
+    int32_t n_objects, n_materials, n_media, n_maps;
+    const PtkObject* objects;
+    const PtkMaterial* materials;
+    const PtkMedium* media;
+    const PtkMap* maps;
+    const double* map_data;
+    int64_t n_map_values;
+    /* triangles of all meshes, in OBJ face order: vertices [n][9], uv [n][6],
+     * vertex normals [n][9], flags [n] */
+    int64_t n_triangles;
+    const double* tri_vertices;
+    const double* tri_uv;
+    const double* tri_normals;
+    const uint8_t* tri_flags;
+    int32_t background_medium, _pad;
+    double background_color[3];
+} PtkSceneDesc;
+
+/* ---- device side ---------------------------------------------------------------- */
+
+typedef struct PtkScene PtkScene; /* device-resident flattened scene + path pools */
+typedef struct PtkFilm PtkFilm;   /* device-resident accumulation buffers */
+
+/* The job unit of the reference's scheduler (Job, app/pathtracer.cpp:26-30) plus the
+ * stream coordinates the reference leaves implicit. */
+typedef struct PtkRenderJob {
+    int64_t start_idx;         /* first linear pixel index */
+    int64_t number_of_pixels;  /* contiguous pixels */
+    int32_t number_of_samples; /* samples added to every pixel of the range */
+    int32_t sample_offset;     /* global index of the first of those samples */
+    uint64_t seed;
+} PtkRenderJob;
+
+typedef struct PtkStats {
+    uint64_t paths;         /* camera samples traced */
+    uint64_t extension_rays;/* closest-hit queries from the path loop */
+    uint64_t shadow_rays;   /* closest-hit queries from visibility marches */
+    uint64_t vertices;      /* surface + scatter vertices shaded */
+    uint64_t bounce_launch_rounds;
+    uint64_t algorithmic_bytes; /* path-state/queue bytes the kernels are specified to move */
+    double extend_ms, shade_ms, connect_ms, other_ms; /* device time per kernel family, HIP events */
+    uint64_t extend_launches, shade_launches, connect_launches;
+    uint64_t extend_bytes, shade_bytes, connect_bytes; /* algorithmic bytes per family */
+} PtkStats;
+
+/* Selects the GPU for this process (hipSetDevice) and creates the library's stream.
+ * Fails with PTK_ERR_DEVICE when no gfx950 device is usable: there is no CPU path. */
+int ptk_init(int device);
+const char* ptk_last_error(void);
+/* Blocks until all work queued by the library on its stream has finished. */
+int ptk_sync(void);
+/* The library's HIP stream as an opaque handle (hipStream_t). */
+void* ptk_stream(void);
+
+/* Replaces Scene construction (src/scene.cpp:546-584) as seen by the render loop:
+ * copies the description to the device, builds the mesh acceleration structure
+ * (replaces BVH::Node::Node, src/bvh.cpp:129-165) and sizes the path pools.
+ * `max_paths_in_flight` <= 0 selects the default.  The caller may free every array of
+ * `desc` on return. */
+int ptk_scene_create(const PtkSceneDesc* desc, int64_t max_paths_in_flight, PtkScene** out);
+void ptk_scene_destroy(PtkScene* scene);
+
+/* Replaces Camera::make_ray + find_closest_hit for one primary ray per pixel of the
+ * range with anti-aliasing as configured (src/camera.cpp:57-70, src/objects.cpp:414-442).
+ * Outputs (host pointers, may be NULL): object index in scene order (-1 = miss),
+ * primitive index within its mesh in OBJ face order (0 otherwise), distance,
+ * intersection point [n][3], normal facing the ray [n][3]. */
+int ptk_trace_primary(PtkScene* scene, const PtkRenderJob* job, int32_t* object_index, int32_t* primitive_index,
+                      double* distance, double* position, double* normal);
+
+/* Replaces raytrace (app/pathtracer.cpp:39-176) for every (pixel, sample) of the job
+ * and returns the un-averaged per-sample results to host arrays laid out
+ * [pixel][sample][3]: radiance, first-surface position, first-surface normal
+ * (PixelData, app/pathtracer.cpp:20-24).  Any pointer may be NULL. */
+int ptk_trace_samples(PtkScene* scene, const PtkRenderJob* job, double* color, double* position, double* normal);
+
+int ptk_film_create(int32_t width, int32_t height, PtkFilm** out);
+void ptk_film_destroy(PtkFilm* film);
+int ptk_film_clear(PtkFilm* film);
+/* Host <-> device copies of the three double[H*W*3] mean buffers and the per-pixel
+ * sample counters (PixelBuffers, include/utils.h:16-20; pixel_counters,
+ * app/pathtracer.cpp:357).  NULL pointers are skipped. */
+int ptk_film_upload(PtkFilm* film, const double* image, const double* position, const double* normal,
+                    const uint64_t* counters);
+int ptk_film_download(PtkFilm* film, double* image, double* position, double* normal, uint64_t* counters);
+/* Device addresses of the film's buffers, for collectives issued by the caller. */
+int ptk_film_device_pointers(PtkFilm* film, double** image, double** position, double** normal,
+                             uint64_t** counters);
+
+/* Replaces raytrace_section (app/pathtracer.cpp:237-275): traces the job and folds
+ * the per-pixel sample means into the film with increment_average's running-mean
+ * arithmetic (app/pathtracer.cpp:232-235).  Asynchronous on the library's stream. */
+int ptk_render(PtkScene* scene, PtkFilm* film, const PtkRenderJob* job);
+
+/* Same, on caller-owned host buffers (the mmap'd temp/raw_*.dat files): uploads the
+ * pixel range, renders, downloads, and returns when the buffers are updated. */
+int ptk_render_host(PtkScene* scene, const PtkRenderJob* job, double* image, double* position, double* normal,
+                    uint64_t* counters);
+
+int ptk_get_stats(PtkScene* scene, PtkStats* stats);
+int ptk_reset_stats(PtkScene* scene);
+
+/* ---- denoise ---------------------------------------------------------------------- */
+
+enum { PTK_DENOISE_ATROUS = 0, PTK_DENOISE_MEDIAN = 1 };
+
+/* DenoisingTask (include/scene.h:31-46). */
+typedef struct PtkDenoiseTask {
+    int32_t mode;
+    int32_t iterations;  /* atrous */
+    double sigma_rt, sigma_x, sigma_n;
+    int32_t kernel_size; /* median */
+    int32_t _pad;
+    double threshold;
+} PtkDenoiseTask;
+
+/* Replaces denoise() (src/denoise.cpp:203-212): applies the tasks in order to `image`
+ * in place, guided by `position` and `normal`; host buffers double[H*W*3]. */
+int ptk_denoise(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t width, int32_t height, double* image,
+                const double* position, const double* normal);
+/* Same on device buffers (image is updated in place; `scratch` is a device buffer of
+ * the same size).  Asynchronous on the library's stream. */
+int ptk_denoise_device(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t width, int32_t height,
+                       double* d_image, const double* d_position, const double* d_normal, double* d_scratch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTK_H */
