@@ -248,6 +248,10 @@ int ptk_render_host(PtkScene* scene, const PtkRenderJob* job, double* image, dou
 
 int ptk_get_stats(PtkScene* scene, PtkStats* stats);
 int ptk_reset_stats(PtkScene* scene);
+/* No counterpart in the reference (it prints two wall-clock spans, app/pathtracer.cpp:309-372):
+ * when enabled, HIP events bracket every kernel family on the library's stream and the
+ * *_ms fields of PtkStats accumulate device time.  Also enabled by PTK_PROFILE=1. */
+int ptk_set_profiling(int enabled);
 
 /* ---- denoise ---------------------------------------------------------------------- */
 

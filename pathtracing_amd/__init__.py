@@ -121,7 +121,7 @@ def load_scene_directory(scene_directory, asset_root=None, **overrides):
         if not hasattr(settings, key):
             raise AttributeError(f"unknown setting {key!r}")
         setattr(settings, key, int(value))
-    return HostScene.load(os.path.join(scene_directory, "scene.json"), settings, asset_root)
+    return HostScene.load(os.path.join(scene_directory, "scene.json"), settings, asset_root or scene_directory)
 
 
 def load_denoising(path, settings):
@@ -179,6 +179,11 @@ def init(device=0):
 
 def sync():
     _check_dev(device_lib().ptk_sync())
+
+
+def set_profiling(enabled):
+    """HIP-event timing of every kernel family into PtkStats.*_ms (costs a few microseconds per launch)."""
+    _check_dev(device_lib().ptk_set_profiling(1 if enabled else 0))
 
 
 class Film:

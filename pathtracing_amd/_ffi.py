@@ -123,6 +123,7 @@ DEVICE_PROTOTYPES = {
     "ptk_render_host": (C.c_int, [C.c_void_p, C.POINTER(PtkRenderJob), dptr, dptr, dptr, u64ptr]),
     "ptk_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PtkStats)]),
     "ptk_reset_stats": (C.c_int, [C.c_void_p]),
+    "ptk_set_profiling": (C.c_int, [C.c_int]),
     "ptk_denoise": (C.c_int, [C.POINTER(PtkDenoiseTask), C.c_int32, C.c_int32, C.c_int32, dptr, dptr, dptr]),
     "ptk_denoise_device": (C.c_int, [C.POINTER(PtkDenoiseTask), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),

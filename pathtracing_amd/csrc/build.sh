@@ -1,0 +1,17 @@
+#!/bin/sh
+# Builds the two product libraries in-tree:
+#   pathtracing_amd/libptkhost.so  host loader (g++)
+#   pathtracing_amd/libptk.so      HIP kernels + C ABI for gfx950 (hipcc cross-compiles without a GPU)
+set -e
+cd "$(dirname "$0")"
+OUT=..
+g++ -std=c++17 -O2 -Wall -Wextra -fPIC -shared -I../../include host/host_loader.cpp -o $OUT/libptkhost.so
+HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -Idevice -I. ${PTK_HIPFLAGS}"
+mkdir -p build
+hipcc $HIPFLAGS -c device/kernels.hip -o build/kernels.o &
+hipcc $HIPFLAGS -c device/denoise.hip -o build/denoise.o &
+hipcc $HIPFLAGS -c ptk_api.hip -o build/ptk_api.o &
+g++ -std=c++17 -O3 -fPIC -I../../include -I. -c host/bvh_builder.cpp -o build/bvh_builder.o &
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC build/kernels.o build/denoise.o build/ptk_api.o build/bvh_builder.o -o $OUT/libptk.so -lpthread
+echo "built $OUT/libptkhost.so $OUT/libptk.so"

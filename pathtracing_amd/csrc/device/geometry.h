@@ -1,0 +1,296 @@
+// Device inlines: ray/primitive tests, BVH traversal, surface attributes, textures.
+// Reference code reproduced: src/objects.cpp (primitive tests, find_closest_hit, normals, UVs),
+// src/bvh.cpp:60-83,179-237 (slab test, ordered traversal), src/valuemap.cpp:34-52.
+#pragma once
+#include "device_math.h"
+#include "scene_device.h"
+
+namespace ptk {
+
+// Ray::prepare (include/utils.h:45-62): dominant axis and shear for the watertight triangle test.
+struct RayPrep {
+    int kx, ky, kz;
+    double Sx, Sy, Sz;
+};
+
+PTK_DEV RayPrep prepare_ray(const V3& d) {
+    RayPrep p;
+    double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
+    int kz = 0;
+    double m = ax;
+    if (ay > m) {
+        kz = 1;
+        m = ay;
+    }
+    if (az > m) kz = 2;
+    int kx = kz + 1;
+    if (kx == 3) kx = 0;
+    int ky = kx + 1;
+    if (ky == 3) ky = 0;
+    double dxp = comp(d, kx), dyp = comp(d, ky), dzp = comp(d, kz);
+    p.kx = kx;
+    p.ky = ky;
+    p.kz = kz;
+    p.Sx = -dxp / dzp;
+    p.Sy = -dyp / dzp;
+    p.Sz = 1.0 / dzp;
+    return p;
+}
+
+PTK_DEV V3 permute(const V3& v, const RayPrep& p) {
+    // kz selects a cyclic rotation of (x, y, z)
+    if (p.kz == 2) return v;
+    if (p.kz == 0) return V3{v.y, v.z, v.x};
+    return V3{v.z, v.x, v.y};
+}
+
+// Triangle::find_closest_object_hit (src/objects.cpp:360-406).
+PTK_DEV bool triangle_hit(const TriHot& t, const V3& o, const RayPrep& rp, double t_max, double& distance) {
+    V3 a = permute(v3(t.p1[0] - o.x, t.p1[1] - o.y, t.p1[2] - o.z), rp);
+    V3 b = permute(v3(t.p2[0] - o.x, t.p2[1] - o.y, t.p2[2] - o.z), rp);
+    V3 c = permute(v3(t.p3[0] - o.x, t.p3[1] - o.y, t.p3[2] - o.z), rp);
+    a.x += rp.Sx * a.z;
+    a.y += rp.Sy * a.z;
+    b.x += rp.Sx * b.z;
+    b.y += rp.Sy * b.z;
+    c.x += rp.Sx * c.z;
+    c.y += rp.Sy * c.z;
+    double e1 = b.x * c.y - b.y * c.x;
+    double e2 = c.x * a.y - c.y * a.x;
+    double e3 = a.x * b.y - a.y * b.x;
+    if ((e1 < 0 || e2 < 0 || e3 < 0) && (e1 > 0 || e2 > 0 || e3 > 0)) return false;
+    double det = e1 + e2 + e3;
+    if (det == 0) return false;
+    double t_scaled = e1 * (a.z * rp.Sz) + e2 * (b.z * rp.Sz) + e3 * (c.z * rp.Sz);
+    if (det < 0 && (t_scaled >= 0 || t_scaled < t_max * det)) return false;
+    if (det > 0 && (t_scaled <= 0 || t_scaled > t_max * det)) return false;
+    distance = t_scaled / det;
+    return true;
+}
+
+// Per-lane traversal stack in LDS, laid out [depth][thread] so that the lanes of a wave touch
+// consecutive banks; entries beyond LDS_STACK_DEPTH spill to a private array.
+struct StackEntry {
+    int32_t node;
+    float tnear;
+};
+
+struct TraversalStack {
+    StackEntry* lds; // this thread's column: element d at lds[d * blockDim.x]
+    int stride;
+    StackEntry spill[SPILL_STACK_DEPTH];
+    int sp;
+    PTK_DEV void push(int32_t node, float tnear) {
+        StackEntry e{node, tnear};
+        if (sp < LDS_STACK_DEPTH) lds[sp * stride] = e;
+        else if (sp < LDS_STACK_DEPTH + SPILL_STACK_DEPTH) spill[sp - LDS_STACK_DEPTH] = e;
+        else return; // deeper than any tree the builder produces (its depth is bounded)
+        sp++;
+    }
+    PTK_DEV StackEntry pop() {
+        sp--;
+        return sp < LDS_STACK_DEPTH ? lds[sp * stride] : spill[sp - LDS_STACK_DEPTH];
+    }
+};
+
+// Closest triangle of one mesh.  Children are visited nearest first and skipped when their entry
+// distance is not below the best hit so far (Node::intersect, src/bvh.cpp:193-213); the slab test is
+// BoundingBox::intersect (:60-83) evaluated on the outward-rounded fp32 boxes.
+PTK_DEV void mesh_closest_hit(const DevScene& sc, const DevObject& o, const V3& org, const V3& dir, const RayPrep& rp,
+                              double& t_best, int& prim_best, TraversalStack& st) {
+    if (o.bvh_root < 0) return;
+    const double idx = 1.0 / dir.x, idy = 1.0 / dir.y, idz = 1.0 / dir.z;
+    st.sp = 0;
+    st.push(o.bvh_root, 0.0f);
+    while (st.sp > 0) {
+        StackEntry e = st.pop();
+        if (static_cast<double>(e.tnear) >= t_best) continue;
+        if (e.node < 0) { // leaf
+            uint32_t code = static_cast<uint32_t>(~e.node);
+            int64_t first = o.first_tri + (code >> 3);
+            int count = static_cast<int>(code & 7u) + 1;
+            for (int i = 0; i < count; i++) {
+                double d;
+                if (triangle_hit(sc.tri_hot[first + i], org, rp, t_best, d) && d > EPSILON && d < t_best) {
+                    t_best = d;
+                    prim_best = static_cast<int>(first + i);
+                }
+            }
+            continue;
+        }
+        const BvhNode4& n = sc.nodes[e.node];
+        float tn[4];
+        int32_t ch[4];
+        int hits = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            int32_t child = n.child[c];
+            double t0 = (static_cast<double>(n.lo_x[c]) - org.x) * idx, t1 = (static_cast<double>(n.hi_x[c]) - org.x) * idx;
+            double lo = fmax(0.0, fmin(t0, t1)), hi = fmax(t0, t1);
+            t0 = (static_cast<double>(n.lo_y[c]) - org.y) * idy;
+            t1 = (static_cast<double>(n.hi_y[c]) - org.y) * idy;
+            lo = fmax(lo, fmin(t0, t1));
+            hi = fmin(hi, fmax(t0, t1));
+            t0 = (static_cast<double>(n.lo_z[c]) - org.z) * idz;
+            t1 = (static_cast<double>(n.hi_z[c]) - org.z) * idz;
+            lo = fmax(lo, fmin(t0, t1));
+            hi = fmin(hi, fmax(t0, t1));
+            bool ok = child != BVH_EMPTY && hi > lo && lo < t_best;
+            if (ok) {
+                // fp32 entry distance rounded down, so the pop-time cull never drops a valid child
+                float f = static_cast<float>(lo);
+                if (static_cast<double>(f) > lo) f = __uint_as_float(__float_as_uint(f) - 1u); // f > lo >= 0: next float down
+                // insertion sort, farthest first
+                int j = hits++;
+                while (j > 0 && tn[j - 1] < f) {
+                    tn[j] = tn[j - 1];
+                    ch[j] = ch[j - 1];
+                    j--;
+                }
+                tn[j] = f;
+                ch[j] = child;
+            }
+        }
+        for (int j = 0; j < hits; j++) st.push(ch[j], tn[j]);
+    }
+}
+
+struct HitInfo {
+    double t;
+    int obj;
+    int prim; // global triangle index (leaf order) for triangles and meshes, 0 otherwise
+};
+
+// find_closest_hit (src/objects.cpp:414-442) without the attribute computation: the linear scan
+// over top-level objects with the shrinking t_max; first object wins exact ties.
+PTK_DEV bool closest_hit(const DevScene& sc, const V3& org, const V3& dir, double t_max, HitInfo& hit, TraversalStack& st) {
+    hit.t = INF;
+    hit.obj = -1;
+    hit.prim = 0;
+    RayPrep rp{};
+    if (sc.has_triangles) rp = prepare_ray(dir);
+    const double dir_dot_org = dot(dir, org);
+    double limit = t_max; // ray.t_max
+    for (int i = 0; i < sc.n_objects; i++) {
+        const DevObject& o = sc.objects[i];
+        double d = INF;
+        int prim = 0;
+        bool success = false;
+        if (o.type == PTK_OBJ_SPHERE) { // :106-119
+            V3 c = v3(o.px, o.py, o.pz);
+            double b = 2 * (dir_dot_org - dot(dir, c));
+            double cc = len2(c - org) - o.radius * o.radius;
+            success = solve_quadratic(b, cc, d) && !(d > limit);
+        }
+        else if (o.type == PTK_OBJ_PLANE || o.type == PTK_OBJ_RECTANGLE) { // :185-211, :237-255
+            V3 n = v3(o.nx, o.ny, o.nz);
+            V3 shifted = org - v3(o.px, o.py, o.pz);
+            double ddn = -dot(dir, n);
+            if (!(fabs(ddn) < EPSILON)) {
+                d = dot(shifted, n) / ddn;
+                success = !(d < EPSILON) && !(d > limit);
+                if (success && o.type == PTK_OBJ_RECTANGLE) {
+                    V3 a1 = v3(o.v1x, o.v1y, o.v1z), a2 = v3(o.v2x, o.v2y, o.v2z);
+                    if (fabs(dot(shifted, a1) + dot(dir, a1) * d) > o.L1 / 2.0 + EPSILON ||
+                        fabs(dot(shifted, a2) + dot(dir, a2) * d) > o.L2 / 2.0 + EPSILON)
+                        success = false;
+                }
+            }
+        }
+        else if (o.type == PTK_OBJ_TRIANGLE) {
+            success = triangle_hit(sc.tri_hot[o.first_tri], org, rp, limit, d);
+            prim = static_cast<int>(o.first_tri);
+        }
+        else { // mesh
+            double tb = limit;
+            int pb = -1;
+            mesh_closest_hit(sc, o, org, dir, rp, tb, pb, st);
+            if (pb >= 0) {
+                success = true;
+                d = tb;
+                prim = pb;
+            }
+        }
+        if (success && d > EPSILON && d < hit.t) {
+            hit.t = d;
+            hit.obj = i;
+            hit.prim = prim;
+            limit = d;
+        }
+    }
+    return hit.obj >= 0;
+}
+
+// ---- surface attributes --------------------------------------------------------------------
+PTK_DEV V3 tri_barycentric(const TriCold& t, const V3& p) { // compute_barycentric :346-353
+    double x = dot(p, v3(t.v1)), y = dot(p, v3(t.v2));
+    double l1 = ((t.y2 - t.y3) * (x - t.x3) + (t.x3 - t.x2) * (y - t.y3)) / t.det_T;
+    double l2 = ((t.y3 - t.y1) * (x - t.x3) + (t.x1 - t.x3) * (y - t.y3)) / t.det_T;
+    return v3(l1, l2, 1.0 - l1 - l2);
+}
+
+PTK_DEV V3 object_normal(const DevScene& sc, const DevObject& o, const V3& p, int prim) { // get_normal_vector
+    if (o.type == PTK_OBJ_SPHERE) return normalize(p - v3(o.px, o.py, o.pz));
+    if (o.type == PTK_OBJ_PLANE || o.type == PTK_OBJ_RECTANGLE) return v3(o.nx, o.ny, o.nz);
+    const TriCold& t = sc.tri_cold[prim];
+    if (t.smooth) { // :334-337
+        V3 b = tri_barycentric(t, p);
+        return normalize(v3(t.n1) * b.x + v3(t.n2) * b.y + v3(t.n3) * b.z);
+    }
+    return v3(t.normal);
+}
+
+PTK_DEV void object_uv(const DevScene& sc, const DevObject& o, const V3& p, int prim, double& u, double& v) { // get_UV
+    if (o.type == PTK_OBJ_SPHERE) { // :96-104
+        V3 unit = (p - v3(o.px, o.py, o.pz)) / o.radius;
+        u = 0.5 + atan2(-unit.z, -unit.x) / (2 * PI);
+        v = 0.5 + asin(-unit.y) / PI;
+    }
+    else if (o.type == PTK_OBJ_PLANE) { // :178-183
+        V3 s = p - v3(o.px, o.py, o.pz);
+        u = 1 - dot(s, v3(o.v1x, o.v1y, o.v1z)) - 0.5;
+        v = 1 - dot(s, v3(o.v2x, o.v2y, o.v2z)) - 0.5;
+    }
+    else if (o.type == PTK_OBJ_RECTANGLE) { // :230-235
+        V3 s = p - v3(o.px, o.py, o.pz);
+        u = 1 - dot(s, v3(o.v1x, o.v1y, o.v1z)) / o.L1 - 0.5;
+        v = 1 - dot(s, v3(o.v2x, o.v2y, o.v2z)) / o.L2 - 0.5;
+    }
+    else { // :355-358
+        const TriCold& t = sc.tri_cold[prim];
+        V3 b = tri_barycentric(t, p);
+        u = t.uv1[0] * b.x + t.uv2[0] * b.y + t.uv3[0] * b.z;
+        v = t.uv1[1] * b.x + t.uv2[1] * b.y + t.uv3[1] * b.z;
+    }
+}
+
+// ---- textures (src/valuemap.cpp:34-52) -----------------------------------------------------
+// Nearest texel, u wrapped, v flipped and wrapped.  1x1 maps skip the address arithmetic (and
+// therefore the reference's "NaN coordinate reads as 0" rule, which needs a NaN UV to matter).
+PTK_DEV int64_t texel_index(const DevMap& m, double u, double v) {
+    int64_t ui = static_cast<int64_t>(static_cast<double>(m.width) * pos_fmod1(u));
+    int64_t vi = static_cast<int64_t>(static_cast<double>(m.height) * pos_fmod1(1 - v));
+    ui = ui < m.width ? ui : m.width - 1; // the products can round up to the size itself
+    vi = vi < m.height ? vi : m.height - 1;
+    return vi * m.width + ui;
+}
+PTK_DEV double tex1(const DevScene& sc, int id, bool use_uv, double u, double v) {
+    if (id < 0) return 0.0;
+    const DevMap& m = sc.maps[id];
+    if (!use_uv || (m.width == 1 && m.height == 1)) return sc.map_data[m.offset];
+    if (isnan(u) || isnan(v)) return 0.0;
+    return sc.map_data[m.offset + texel_index(m, u, v)];
+}
+PTK_DEV V3 tex3(const DevScene& sc, int id, bool use_uv, double u, double v) {
+    if (id < 0) return v3(0.0);
+    const DevMap& m = sc.maps[id];
+    int64_t i = 0;
+    if (use_uv && !(m.width == 1 && m.height == 1)) {
+        if (isnan(u) || isnan(v)) return v3(0.0);
+        i = 3 * texel_index(m, u, v);
+    }
+    const double* p = sc.map_data + m.offset + i;
+    return v3(p[0], p[1], p[2]);
+}
+
+} // namespace ptk

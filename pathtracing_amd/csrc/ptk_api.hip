@@ -1,0 +1,939 @@
+// C ABI of the GPU library (include/ptk.h): scene flattening, path-pool management, the bounce
+// loop that drives the wavefront kernels, film accumulation, denoise entry points.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "device/kernels.h"
+#include "host/bvh_builder.h"
+#include "ptk.h"
+
+using namespace ptk;
+
+namespace {
+
+thread_local std::string g_error;
+hipStream_t g_stream = nullptr;
+int g_device = -1;
+bool g_profiling = false;
+
+int fail(int code, const std::string& message) {
+    g_error = message;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                        \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(PTK_ERR_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(e_));          \
+    } while (0)
+
+int require_init() {
+    if (g_device < 0) return fail(PTK_ERR_DEVICE, "ptk_init() has not been called (or no GPU is available)");
+    return PTK_OK;
+}
+
+// ---- host double[3] helpers in the reference's operation order ---------------------------------
+struct H3 {
+    double x, y, z;
+};
+H3 h3(const double* p) { return H3{p[0], p[1], p[2]}; }
+H3 sub(H3 a, H3 b) { return H3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+double hdot(H3 a, H3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+H3 hcross(H3 a, H3 b) { return H3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+H3 hnormalize(H3 a) {
+    double l = std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+    return H3{a.x / l, a.y / l, a.z / l};
+}
+void put(double* dst, H3 v) {
+    dst[0] = v.x;
+    dst[1] = v.y;
+    dst[2] = v.z;
+}
+H3 rotate_yzx(H3 p, double alpha, double beta, double gamma) { // src/utils.cpp:143-173
+    double a = alpha * M_PI / 180, b = beta * M_PI / 180, g = gamma * M_PI / 180;
+    double ca = std::cos(a), sa = std::sin(a), cb = std::cos(b), sb = std::sin(b), cg = std::cos(g), sg = std::sin(g);
+    return H3{p.x * (ca * cb) + p.y * (sa * sg - ca * cg * sb) + p.z * (cg * sa + ca * sb * sg),
+              p.x * (sb) + p.y * (cb * cg) + p.z * (-cb * sg),
+              p.x * (-cb * sa) + p.y * (ca * sg + cg * sa * sb) + p.z * (ca * cg - sa * sb * sg)};
+}
+
+// Triangle::Triangle (src/objects.cpp:269-299) + set_vertex_UV / set_vertex_normals.
+void make_triangle(const double* p, const double* uv, const double* nrm, uint8_t flags, int32_t face, TriHot& hot, TriCold& cold) {
+    H3 p1 = h3(p), p2 = h3(p + 3), p3 = h3(p + 6);
+    put(hot.p1, p1);
+    put(hot.p2, p2);
+    put(hot.p3, p3);
+    H3 v1 = sub(p2, p1), v2 = sub(p3, p1);
+    H3 normal = hnormalize(hcross(v1, v2));
+    v1 = hnormalize(v1);
+    v2 = hnormalize(hcross(normal, v1));
+    put(cold.normal, normal);
+    put(cold.v1, v1);
+    put(cold.v2, v2);
+    cold.x1 = hdot(p1, v1);
+    cold.y1 = hdot(p1, v2);
+    cold.x2 = hdot(p2, v1);
+    cold.y2 = hdot(p2, v2);
+    cold.x3 = hdot(p3, v1);
+    cold.y3 = hdot(p3, v2);
+    cold.det_T = (cold.y2 - cold.y3) * (cold.x1 - cold.x3) + (cold.x3 - cold.x2) * (cold.y1 - cold.y3);
+    cold.area = 0.5 * std::abs(cold.x1 * (cold.y2 - cold.y3) + cold.x2 * (cold.y3 - cold.y1) + cold.x3 * (cold.y1 - cold.y2));
+    for (int i = 0; i < 2; i++) {
+        cold.uv1[i] = (flags & PTK_TRI_HAS_UV) ? uv[i] : 0.0;
+        cold.uv2[i] = (flags & PTK_TRI_HAS_UV) ? uv[2 + i] : 0.0;
+        cold.uv3[i] = (flags & PTK_TRI_HAS_UV) ? uv[4 + i] : 0.0;
+    }
+    if (flags & PTK_TRI_SMOOTH) {
+        put(cold.n1, h3(nrm));
+        put(cold.n2, h3(nrm + 3));
+        put(cold.n3, h3(nrm + 6));
+        cold.smooth = 1;
+    }
+    else {
+        put(cold.n1, normal);
+        put(cold.n2, normal);
+        put(cold.n3, normal);
+        cold.smooth = 0;
+    }
+    cold.face_index = face;
+}
+
+struct DeviceBuffers {
+    std::vector<void*> allocations;
+    DeviceBuffers() = default;
+    DeviceBuffers(const DeviceBuffers&) = delete;
+    DeviceBuffers& operator=(const DeviceBuffers&) = delete;
+    ~DeviceBuffers() { free_all(); }
+    void free_all() {
+        for (void* p : allocations) (void) hipFree(p);
+        allocations.clear();
+    }
+    template<typename T>
+    hipError_t alloc(T** out, size_t count) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) allocations.push_back(p);
+        *out = static_cast<T*>(p);
+        return e;
+    }
+    template<typename T>
+    hipError_t upload(const T** out, const std::vector<T>& host) {
+        T* p = nullptr;
+        hipError_t e = alloc(&p, host.size());
+        if (e == hipSuccess && !host.empty()) e = hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice);
+        *out = p;
+        return e;
+    }
+    void release(void* p) {
+        auto it = std::find(allocations.begin(), allocations.end(), p);
+        if (it != allocations.end()) {
+            (void) hipFree(p);
+            allocations.erase(it);
+        }
+    }
+};
+
+constexpr int64_t DEFAULT_MAX_PATHS = int64_t(1) << 24;
+
+} // namespace
+
+struct PtkFilm {
+    int32_t width = 0, height = 0;
+    double *image = nullptr, *position = nullptr, *normal = nullptr;
+    unsigned long long* counters = nullptr;
+};
+
+struct PtkScene {
+    DevScene dev{};
+    PtkSettings settings{};
+    DeviceBuffers scene_buffers; // tables, triangles, nodes
+    DeviceBuffers pool_buffers;  // path state, queues, results
+    int64_t max_paths = DEFAULT_MAX_PATHS;
+    int64_t capacity = 0;
+    PathPool pool[2]{};
+    HitRecords hits{};
+    uint32_t* queues = nullptr; // [N_CLASSES][capacity]
+    ShadowQueue shadow{};
+    SampleResults results{};
+    BounceCounters* d_counters = nullptr;
+    BounceCounters* h_counters = nullptr; // pinned
+    unsigned long long* d_ray_counter = nullptr;
+    std::vector<int> classes; // queue classes present in the scene
+    PtkFilm* host_film = nullptr; // scratch film for ptk_render_host
+    PtkStats stats{};
+    std::vector<hipEvent_t> events;
+};
+
+namespace {
+
+int ensure_capacity(PtkScene* s, int64_t paths) {
+    if (paths <= s->capacity) return PTK_OK;
+    s->pool_buffers.free_all(); // the previous, smaller pools
+    s->capacity = 0;
+    const size_t n = static_cast<size_t>(paths);
+    DeviceBuffers& b = s->pool_buffers;
+    for (int k = 0; k < 2; k++) {
+        PathPool& p = s->pool[k];
+        double** fields[] = {&p.ox, &p.oy, &p.oz, &p.dx, &p.dy, &p.dz, &p.tx, &p.ty, &p.tz, &p.sx, &p.sy, &p.sz, &p.spdf};
+        for (double** f : fields) HIP_TRY(b.alloc(f, n));
+        HIP_TRY(b.alloc(&p.sid, n));
+        HIP_TRY(b.alloc(&p.ctr, n));
+        HIP_TRY(b.alloc(&p.flags, n));
+    }
+    HIP_TRY(b.alloc(&s->hits.t, n));
+    HIP_TRY(b.alloc(&s->hits.obj, n));
+    HIP_TRY(b.alloc(&s->hits.prim, n));
+    HIP_TRY(b.alloc(&s->queues, n * N_CLASSES));
+    {
+        ShadowQueue& q = s->shadow;
+        double** fields[] = {&q.ox, &q.oy, &q.oz, &q.dx, &q.dy, &q.dz, &q.dist, &q.cr, &q.cg, &q.cb};
+        for (double** f : fields) HIP_TRY(b.alloc(f, n));
+        HIP_TRY(b.alloc(&q.key, n));
+        HIP_TRY(b.alloc(&q.sid, n));
+        HIP_TRY(b.alloc(&q.info, n));
+    }
+    {
+        SampleResults& r = s->results;
+        double** fields[] = {&r.cr, &r.cg, &r.cb, &r.px, &r.py, &r.pz, &r.nx, &r.ny, &r.nz};
+        for (double** f : fields) HIP_TRY(b.alloc(f, n));
+    }
+    s->capacity = paths;
+    return PTK_OK;
+}
+
+// bytes the kernels are specified to move per item (path-state, hit, queue and shadow records)
+constexpr uint64_t EXTEND_BYTES_PER_PATH = 6 * 8 + 4 + 16 + 4;              // ray + flags in; hit record + queue index out
+constexpr uint64_t SHADE_BYTES_PER_PATH = (13 * 8 + 12) + 16 + 4;           // state + hit + queue index in
+constexpr uint64_t SHADE_BYTES_PER_SURVIVOR = 13 * 8 + 12;                  // state out
+constexpr uint64_t SHADE_BYTES_PER_SHADOW = 10 * 8 + 8 + 4 + 4;             // shadow record out
+constexpr uint64_t CONNECT_BYTES_PER_SHADOW = 10 * 8 + 8 + 4 + 4 + 2 * 24;  // record in + radiance read-modify-write
+constexpr uint64_t GENERATE_BYTES_PER_PATH = (13 * 8 + 12) + 9 * 8;         // state + zeroed results out
+constexpr uint64_t ACCUMULATE_BYTES_PER_PATH = 9 * 8;                       // results in
+
+struct EventTimer {
+    PtkScene* s;
+    size_t next = 0;
+    std::vector<std::pair<int, std::pair<size_t, size_t>>> spans; // family, (begin, end)
+    hipEvent_t get() {
+        if (next == s->events.size()) {
+            hipEvent_t e;
+            (void) hipEventCreate(&e);
+            s->events.push_back(e);
+        }
+        return s->events[next++];
+    }
+    void begin(int family) {
+        if (!g_profiling) return;
+        hipEvent_t e = get();
+        (void) hipEventRecord(e, g_stream);
+        spans.push_back({family, {next - 1, 0}});
+    }
+    void end() {
+        if (!g_profiling) return;
+        hipEvent_t e = get();
+        (void) hipEventRecord(e, g_stream);
+        spans.back().second.second = next - 1;
+    }
+    void collect() {
+        if (!g_profiling) return;
+        (void) hipStreamSynchronize(g_stream);
+        for (auto& sp : spans) {
+            float ms = 0;
+            (void) hipEventElapsedTime(&ms, s->events[sp.second.first], s->events[sp.second.second]);
+            switch (sp.first) {
+                case 0: s->stats.extend_ms += ms; break;
+                case 1: s->stats.shade_ms += ms; break;
+                case 2: s->stats.connect_ms += ms; break;
+                default: s->stats.other_ms += ms; break;
+            }
+        }
+        spans.clear();
+        next = 0;
+    }
+};
+
+// Traces one batch (all samples of a contiguous pixel range) to completion; per-sample results
+// are left in s->results.
+int trace_batch(PtkScene* s, const BatchParams& b) {
+    EventTimer timer{s};
+    PtkStats& st = s->stats;
+    timer.begin(3);
+    launch_generate(g_stream, s->dev, b, s->pool[0], s->results);
+    timer.end();
+    st.paths += b.n_paths;
+    st.algorithmic_bytes += GENERATE_BYTES_PER_PATH * b.n_paths;
+    uint32_t n_active = b.n_paths;
+    int cur = 0;
+    HIP_TRY(hipMemsetAsync(s->d_ray_counter, 0, sizeof(unsigned long long), g_stream));
+    for (int depth = 0; depth <= s->settings.max_recursion_depth && n_active > 0; depth++) {
+        HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(BounceCounters), g_stream));
+        timer.begin(0);
+        launch_extend(g_stream, s->dev, b, s->pool[cur], n_active, s->hits, s->queues, static_cast<uint32_t>(s->capacity),
+                      s->d_counters, s->results);
+        timer.end();
+        timer.begin(1);
+        for (int cls : s->classes)
+            launch_shade(g_stream, cls, n_active, s->dev, b, s->pool[cur], s->pool[cur ^ 1], s->hits,
+                         s->queues + static_cast<size_t>(cls) * static_cast<size_t>(s->capacity), s->d_counters, s->shadow,
+                         s->results);
+        timer.end();
+        if (s->settings.enable_next_event_estimation) {
+            timer.begin(2);
+            launch_connect(g_stream, n_active, s->dev, s->shadow, s->d_counters, s->results, s->d_ray_counter);
+            timer.end();
+        }
+        HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, sizeof(BounceCounters), hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        const BounceCounters& c = *s->h_counters;
+        uint64_t shaded = 0;
+        for (int k = 0; k < N_CLASSES; k++) shaded += c.queue_count[k];
+        st.extension_rays += n_active;
+        st.vertices += shaded;
+        st.bounce_launch_rounds++;
+        st.extend_launches++;
+        st.shade_launches += s->classes.size();
+        st.connect_launches += s->settings.enable_next_event_estimation ? 1 : 0;
+        const uint64_t eb = EXTEND_BYTES_PER_PATH * n_active;
+        const uint64_t sb = SHADE_BYTES_PER_PATH * shaded + SHADE_BYTES_PER_SURVIVOR * c.n_next + SHADE_BYTES_PER_SHADOW * c.n_shadow;
+        const uint64_t cb = CONNECT_BYTES_PER_SHADOW * c.n_shadow;
+        st.extend_bytes += eb;
+        st.shade_bytes += sb;
+        st.connect_bytes += cb;
+        st.algorithmic_bytes += eb + sb + cb;
+        n_active = c.n_next;
+        cur ^= 1;
+    }
+    unsigned long long shadow_rays = 0;
+    HIP_TRY(hipMemcpyAsync(&shadow_rays, s->d_ray_counter, sizeof(shadow_rays), hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    st.shadow_rays += shadow_rays;
+    timer.collect();
+    return PTK_OK;
+}
+
+int check_job(const PtkScene* s, const PtkRenderJob* job, const char* who) {
+    if (!s || !job) return fail(PTK_ERR_INVALID, std::string(who) + ": null argument");
+    const int64_t n = static_cast<int64_t>(s->settings.width) * s->settings.height;
+    if (job->start_idx < 0 || job->number_of_pixels < 0 || job->start_idx + job->number_of_pixels > n)
+        return fail(PTK_ERR_INVALID, std::string(who) + ": pixel range outside the image");
+    if (job->number_of_samples < 0 || job->sample_offset < 0) return fail(PTK_ERR_INVALID, std::string(who) + ": negative sample count");
+    if (job->number_of_samples > s->max_paths)
+        return fail(PTK_ERR_MEMORY, std::string(who) + ": number_of_samples exceeds the paths-in-flight limit");
+    return PTK_OK;
+}
+
+// Splits a job into batches of whole pixels and calls `after_batch(batch, first_pixel_of_batch_in_job)`.
+template<typename F>
+int for_each_batch(PtkScene* s, const PtkRenderJob* job, F&& after_batch) {
+    if (job->number_of_pixels == 0 || job->number_of_samples == 0) return PTK_OK;
+    const int64_t per_batch = std::max<int64_t>(1, s->max_paths / job->number_of_samples);
+    const int64_t batch_pixels = std::min<int64_t>(per_batch, job->number_of_pixels);
+    int rc = ensure_capacity(s, batch_pixels * job->number_of_samples);
+    if (rc != PTK_OK) return rc;
+    for (int64_t p = 0; p < job->number_of_pixels; p += batch_pixels) {
+        BatchParams b{};
+        b.start_idx = job->start_idx + p;
+        b.n_pixels = static_cast<uint32_t>(std::min<int64_t>(batch_pixels, job->number_of_pixels - p));
+        b.n_samples = static_cast<uint32_t>(job->number_of_samples);
+        b.sample_offset = static_cast<uint32_t>(job->sample_offset);
+        b.n_paths = b.n_pixels * b.n_samples;
+        b.seed = job->seed;
+        rc = trace_batch(s, b);
+        if (rc != PTK_OK) return rc;
+        rc = after_batch(b, p);
+        if (rc != PTK_OK) return rc;
+    }
+    return PTK_OK;
+}
+
+} // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* ptk_last_error(void) {
+    return g_error.c_str();
+}
+
+int ptk_init(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(PTK_ERR_DEVICE, "no HIP device available: this library has no CPU path");
+    if (device < 0 || device >= count) return fail(PTK_ERR_INVALID, "ptk_init: device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PTK_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", but the kernels are built for gfx950 only");
+    if (g_stream && g_device != device) {
+        (void) hipStreamDestroy(g_stream);
+        g_stream = nullptr;
+    }
+    if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_device = device;
+    const char* prof = std::getenv("PTK_PROFILE");
+    if (prof && prof[0] == '1') g_profiling = true;
+    return PTK_OK;
+}
+
+int ptk_set_profiling(int enabled) {
+    g_profiling = enabled != 0;
+    return PTK_OK;
+}
+
+int ptk_sync(void) {
+    if (require_init() != PTK_OK) return PTK_ERR_DEVICE;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return PTK_OK;
+}
+
+void* ptk_stream(void) {
+    return g_stream;
+}
+
+int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScene** out) {
+    if (!d || !out) return fail(PTK_ERR_INVALID, "ptk_scene_create: null argument");
+    *out = nullptr;
+    if (require_init() != PTK_OK) return PTK_ERR_DEVICE;
+    if (d->settings.width < 1 || d->settings.height < 1) return fail(PTK_ERR_INVALID, "ptk_scene_create: empty image");
+    if (static_cast<int64_t>(d->settings.width) * d->settings.height > (int64_t(1) << 31))
+        return fail(PTK_ERR_INVALID, "ptk_scene_create: image larger than 2^31 pixels");
+    if (d->n_objects < 0 || d->n_objects > 65535) return fail(PTK_ERR_INVALID, "ptk_scene_create: at most 65535 top-level objects");
+    if (d->n_media < 1 || d->n_media > 65534) return fail(PTK_ERR_INVALID, "ptk_scene_create: between 1 and 65534 media required");
+    if (d->settings.max_recursion_depth < 0 || d->settings.max_recursion_depth > 8000)
+        return fail(PTK_ERR_INVALID, "ptk_scene_create: max_recursion_depth must be in [0, 8000]");
+    if (d->background_medium < 0 || d->background_medium >= d->n_media)
+        return fail(PTK_ERR_INVALID, "ptk_scene_create: background_medium out of range");
+    if (d->n_triangles > (int64_t(1) << 28)) return fail(PTK_ERR_INVALID, "ptk_scene_create: at most 2^28 triangles");
+
+    std::unique_ptr<PtkScene> s(new PtkScene());
+    s->settings = d->settings;
+    s->max_paths = max_paths_in_flight > 0 ? max_paths_in_flight : DEFAULT_MAX_PATHS;
+    DevScene& dev = s->dev;
+    DeviceBuffers& buf = s->scene_buffers;
+
+    // maps
+    std::vector<DevMap> maps(static_cast<size_t>(d->n_maps));
+    for (int i = 0; i < d->n_maps; i++) {
+        const PtkMap& m = d->maps[i];
+        if (m.width < 1 || m.height < 1 || (m.dim != 1 && m.dim != 3) || m.offset < 0 ||
+            m.offset + static_cast<int64_t>(m.width) * m.height * m.dim > d->n_map_values)
+            return fail(PTK_ERR_INVALID, "ptk_scene_create: malformed map table");
+        maps[static_cast<size_t>(i)] = DevMap{m.width, m.height, m.dim, 0, m.offset};
+    }
+    std::vector<double> map_data(d->map_data, d->map_data + d->n_map_values);
+
+    // media (Medium::Medium src/medium.cpp:4-11; BeersLawMedium drops scattering :37-39)
+    std::vector<DevMedium> media(static_cast<size_t>(d->n_media));
+    bool any_scattering = false;
+    for (int i = 0; i < d->n_media; i++) {
+        const PtkMedium& pm = d->media[i];
+        DevMedium m{};
+        m.type = pm.type;
+        m.ior = pm.refractive_index;
+        for (int k = 0; k < 3; k++) {
+            m.absorption[k] = pm.absorption[k];
+            m.scattering[k] = pm.type == PTK_MEDIUM_BEERS_LAW ? 0.0 : pm.scattering[k];
+            m.emission[k] = pm.emission[k];
+            m.extinction[k] = m.absorption[k] + m.scattering[k];
+        }
+        m.is_clear = m.extinction[0] == 0 && m.extinction[1] == 0 && m.extinction[2] == 0;
+        any_scattering |= pm.type == PTK_MEDIUM_HOMOGENEOUS_SCATTERING;
+        media[static_cast<size_t>(i)] = m;
+    }
+
+    // materials (Material::Material src/materials.cpp:3-43; ensure_metallic :322-327)
+    auto map_ok = [&](int id, int dim) { return id == -1 || (id >= 0 && id < d->n_maps && d->maps[id].dim == dim); };
+    auto map_big = [&](int id) { return id >= 0 && (d->maps[id].width > 1 || d->maps[id].height > 1); };
+    std::vector<DevMaterial> materials(static_cast<size_t>(d->n_materials));
+    for (int i = 0; i < d->n_materials; i++) {
+        const PtkMaterial& pm = d->materials[i];
+        if (pm.type < 0 || pm.type >= PTK_MAT_COUNT) return fail(PTK_ERR_INVALID, "ptk_scene_create: unknown material type");
+        if (!map_ok(pm.albedo_map, 3) || !map_ok(pm.emission_color_map, 3) || !map_ok(pm.light_intensity_map, 1) ||
+            !map_ok(pm.roughness_map, 1) || !map_ok(pm.transparency_map, 1))
+            return fail(PTK_ERR_INVALID, "ptk_scene_create: material refers to a missing map or one of the wrong channel count");
+        if (pm.internal_medium < -1 || pm.internal_medium >= d->n_media || pm.external_medium < -1 || pm.external_medium >= d->n_media)
+            return fail(PTK_ERR_INVALID, "ptk_scene_create: material refers to a missing medium");
+        DevMaterial m{};
+        m.type = pm.type;
+        m.is_light = pm.is_light_source != 0;
+        m.is_dielectric = pm.is_dielectric != 0;
+        if (pm.type == PTK_MAT_METALLIC_MICROFACET || pm.type == PTK_MAT_REFLECTIVE_MICROFACET) m.is_dielectric = 0;
+        m.n = pm.surface_refractive_index;
+        m.k = m.is_dielectric ? 0.0 : pm.extinction_coefficient;
+        m.albedo = pm.albedo_map;
+        m.emission = pm.emission_color_map;
+        m.intensity = pm.light_intensity_map;
+        m.roughness = pm.roughness_map;
+        m.transparency = pm.transparency_map;
+        m.internal_medium = pm.internal_medium;
+        m.external_medium = pm.external_medium;
+        m.needs_uv = map_big(m.albedo) || map_big(m.emission) || map_big(m.intensity) || map_big(m.roughness) || map_big(m.transparency);
+        materials[static_cast<size_t>(i)] = m;
+    }
+
+    // objects and triangles
+    std::vector<DevObject> objects(static_cast<size_t>(d->n_objects));
+    std::vector<TriHot> tri_hot;
+    std::vector<TriCold> tri_cold;
+    std::vector<BvhNode4> nodes;
+    std::vector<double> light_area;
+    std::vector<int32_t> light_tri;
+    std::vector<int32_t> lights;
+    uint32_t class_mask = any_scattering ? (1u << CLASS_SCATTER) : 0u;
+    const int build_threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    for (int i = 0; i < d->n_objects; i++) {
+        const PtkObject& po = d->objects[i];
+        if (po.material < 0 || po.material >= d->n_materials) return fail(PTK_ERR_INVALID, "ptk_scene_create: object refers to a missing material");
+        DevObject o{};
+        o.type = po.type;
+        o.material = po.material;
+        o.is_light = materials[static_cast<size_t>(po.material)].is_light;
+        o.bvh_root = -1;
+        class_mask |= 1u << materials[static_cast<size_t>(po.material)].type;
+        if (o.is_light) lights.push_back(i);
+        switch (po.type) {
+            case PTK_OBJ_SPHERE: // Sphere::Sphere src/objects.cpp:90-94
+                o.px = po.position[0];
+                o.py = po.position[1];
+                o.pz = po.position[2];
+                o.radius = po.radius;
+                o.area = 4 * M_PI * o.radius * o.radius;
+                break;
+            case PTK_OBJ_PLANE:
+            case PTK_OBJ_RECTANGLE: { // Plane::Plane :170-176, Rectangle::Rectangle :223-229
+                o.px = po.position[0];
+                o.py = po.position[1];
+                o.pz = po.position[2];
+                H3 v1 = hnormalize(h3(po.v1)), v2 = hnormalize(h3(po.v2));
+                H3 n = hnormalize(hcross(v1, v2));
+                o.v1x = v1.x;
+                o.v1y = v1.y;
+                o.v1z = v1.z;
+                o.v2x = v2.x;
+                o.v2y = v2.y;
+                o.v2z = v2.z;
+                o.nx = n.x;
+                o.ny = n.y;
+                o.nz = n.z;
+                if (po.type == PTK_OBJ_RECTANGLE) {
+                    o.L1 = po.L1;
+                    o.L2 = po.L2;
+                    o.area = o.L1 * o.L2;
+                }
+                break;
+            }
+            case PTK_OBJ_TRIANGLE: {
+                double p[9];
+                std::memcpy(p, po.position, 24);
+                std::memcpy(p + 3, po.v1, 24);
+                std::memcpy(p + 6, po.v2, 24);
+                TriHot hot{};
+                TriCold cold{};
+                make_triangle(p, nullptr, nullptr, 0, 0, hot, cold);
+                o.first_tri = static_cast<int64_t>(tri_hot.size());
+                o.n_tri = 1;
+                o.area = cold.area;
+                tri_hot.push_back(hot);
+                tri_cold.push_back(cold);
+                break;
+            }
+            case PTK_OBJ_MESH: {
+                if (po.first_triangle < 0 || po.n_triangles < 0 || po.first_triangle + po.n_triangles > d->n_triangles)
+                    return fail(PTK_ERR_INVALID, "ptk_scene_create: mesh triangle range out of bounds");
+                const int64_t n = po.n_triangles;
+                o.first_tri = static_cast<int64_t>(tri_hot.size());
+                o.n_tri = n;
+                if (n == 0) break;
+                const double* verts = d->tri_vertices + 9 * po.first_triangle;
+                BuiltBvh bvh = build_bvh4(verts, n, d->settings.bvh_leaf_size, d->settings.bvh_n_axis_splits, build_threads);
+                if (3 * bvh.max_depth + 1 > LDS_STACK_DEPTH + SPILL_STACK_DEPTH)
+                    return fail(PTK_ERR_MEMORY, "ptk_scene_create: mesh hierarchy deeper than the traversal stack allows");
+                std::vector<int32_t> leaf_position(static_cast<size_t>(n)); // face -> position in leaf order
+                for (int64_t k = 0; k < n; k++) leaf_position[bvh.order[static_cast<size_t>(k)]] = static_cast<int32_t>(k);
+                const size_t base = tri_hot.size();
+                tri_hot.resize(base + static_cast<size_t>(n));
+                tri_cold.resize(base + static_cast<size_t>(n));
+                double area = 0; // ObjectUnion::ObjectUnion sums in face order (src/objectunion.cpp:9-14)
+                std::vector<double> face_area(static_cast<size_t>(n));
+                for (int64_t f = 0; f < n; f++) {
+                    const int64_t g = po.first_triangle + f;
+                    const size_t slot = base + static_cast<size_t>(leaf_position[static_cast<size_t>(f)]);
+                    make_triangle(d->tri_vertices + 9 * g, d->tri_uv + 6 * g, d->tri_normals + 9 * g, d->tri_flags[g],
+                                  static_cast<int32_t>(f), tri_hot[slot], tri_cold[slot]);
+                    face_area[static_cast<size_t>(f)] = tri_cold[slot].area;
+                    area += tri_cold[slot].area;
+                }
+                o.area = area;
+                o.bvh_root = static_cast<int32_t>(nodes.size());
+                const int32_t node_base = static_cast<int32_t>(nodes.size());
+                for (BvhNode4 node : bvh.nodes) {
+                    for (int c = 0; c < 4; c++)
+                        if (node.child[c] >= 0) node.child[c] += node_base;
+                    nodes.push_back(node);
+                }
+                if (o.is_light) {
+                    // The reference's area table is filled in face order before the BVH root sorts the
+                    // triangle array in place, and is then used to index the sorted array
+                    // (src/objectunion.cpp:19-43, :100-142).  Reproduce both orders.
+                    o.n_light_tris = static_cast<int32_t>(n);
+                    o.light_table = static_cast<int64_t>(light_area.size());
+                    double c = 0;
+                    for (int64_t f = 0; f < n; f++) {
+                        c = f == 0 ? face_area[0] : face_area[static_cast<size_t>(f)] + c;
+                        light_area.push_back(c);
+                    }
+                    o.mesh_light_area = c;
+                    std::vector<int> sorted(static_cast<size_t>(n));
+                    for (int64_t f = 0; f < n; f++) sorted[static_cast<size_t>(f)] = static_cast<int>(f);
+                    if (n > d->settings.bvh_leaf_size) { // root Node::Node: get_split_axis + sort_by_axis (src/bvh.cpp:129-177)
+                        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                        for (int64_t f = 0; f < n; f++)
+                            for (int v = 0; v < 3; v++)
+                                for (int a = 0; a < 3; a++) {
+                                    lo[a] = std::min(lo[a], verts[9 * f + 3 * v + a]);
+                                    hi[a] = std::max(hi[a], verts[9 * f + 3 * v + a]);
+                                }
+                        int axis = 0;
+                        double max_length = 0;
+                        for (int a = 0; a < 3; a++) {
+                            double length = (hi[a] + EPSILON) - (lo[a] - EPSILON);
+                            if (length >= max_length) {
+                                axis = a;
+                                max_length = length;
+                            }
+                        }
+                        std::sort(sorted.begin(), sorted.end(), [verts, axis](int a, int b) {
+                            double ca = (verts[9 * a + axis] + verts[9 * a + 3 + axis] + verts[9 * a + 6 + axis]) / 3.0;
+                            double cb = (verts[9 * b + axis] + verts[9 * b + 3 + axis] + verts[9 * b + 6 + axis]) / 3.0;
+                            return ca < cb;
+                        });
+                    }
+                    for (int64_t k = 0; k < n; k++)
+                        light_tri.push_back(static_cast<int32_t>(base) + leaf_position[static_cast<size_t>(sorted[static_cast<size_t>(k)])]);
+                }
+                break;
+            }
+            default: return fail(PTK_ERR_INVALID, "ptk_scene_create: unknown object type");
+        }
+        objects[static_cast<size_t>(i)] = o;
+    }
+
+    // camera (Camera::Camera src/camera.cpp:4-22)
+    const PtkCamera& c = d->camera;
+    H3 view = rotate_yzx(H3{0, -1, 0}, c.orientation_y, c.orientation_z, c.orientation_x);
+    H3 screen_y = rotate_yzx(H3{0, 0, -1}, c.orientation_y, c.orientation_z, c.orientation_x);
+    H3 screen_x = hcross(view, screen_y);
+    std::memcpy(dev.cam.pos, c.position, 24);
+    put(dev.cam.view, view);
+    put(dev.cam.screen_x, screen_x);
+    put(dev.cam.screen_y, screen_y);
+    dev.cam.width = c.camera_width;
+    dev.cam.screen_height = c.camera_width * static_cast<double>(d->settings.height) / static_cast<double>(d->settings.width);
+    dev.cam.focal = c.focal_length;
+    dev.cam.aperture = c.aperture_size;
+    dev.cam.focus = c.focus_distance;
+    dev.cam.dof_mode = c.dof_mode;
+
+    dev.n_objects = d->n_objects;
+    dev.n_materials = d->n_materials;
+    dev.n_media = d->n_media;
+    dev.n_maps = d->n_maps;
+    dev.n_lights = static_cast<int32_t>(lights.size());
+    dev.has_triangles = !tri_hot.empty();
+    dev.width = d->settings.width;
+    dev.height = d->settings.height;
+    dev.max_depth = d->settings.max_recursion_depth;
+    dev.min_depth = d->settings.min_recursion_steps;
+    dev.nee = d->settings.enable_next_event_estimation != 0;
+    dev.aa = d->settings.enable_anti_aliasing != 0;
+    dev.background_medium = d->background_medium;
+    std::memcpy(dev.background, d->background_color, 24);
+    dev.background_is_black = d->background_color[0] == 0 && d->background_color[1] == 0 && d->background_color[2] == 0;
+    dev.class_mask = class_mask;
+    for (int k = 0; k < N_CLASSES; k++)
+        if ((class_mask >> k) & 1u) s->classes.push_back(k);
+
+    HIP_TRY(buf.upload(&dev.objects, objects));
+    HIP_TRY(buf.upload(&dev.materials, materials));
+    HIP_TRY(buf.upload(&dev.media, media));
+    HIP_TRY(buf.upload(&dev.maps, maps));
+    HIP_TRY(buf.upload(&dev.map_data, map_data));
+    HIP_TRY(buf.upload(&dev.lights, lights));
+    HIP_TRY(buf.upload(&dev.tri_hot, tri_hot));
+    HIP_TRY(buf.upload(&dev.tri_cold, tri_cold));
+    HIP_TRY(buf.upload(&dev.nodes, nodes));
+    HIP_TRY(buf.upload(&dev.light_cumulative_area, light_area));
+    HIP_TRY(buf.upload(&dev.light_tri_index, light_tri));
+    HIP_TRY(buf.alloc(&s->d_counters, 1));
+    HIP_TRY(buf.alloc(&s->d_ray_counter, 1));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), sizeof(BounceCounters), hipHostMallocDefault));
+    *out = s.release();
+    return PTK_OK;
+}
+
+void ptk_scene_destroy(PtkScene* scene) {
+    if (!scene) return;
+    if (g_stream) (void) hipStreamSynchronize(g_stream);
+    if (scene->h_counters) (void) hipHostFree(scene->h_counters);
+    for (hipEvent_t e : scene->events) (void) hipEventDestroy(e);
+    if (scene->host_film) ptk_film_destroy(scene->host_film);
+    delete scene;
+}
+
+int ptk_trace_primary(PtkScene* s, const PtkRenderJob* job, int32_t* object_index, int32_t* primitive_index, double* distance,
+                      double* position, double* normal) {
+    int rc = check_job(s, job, "ptk_trace_primary");
+    if (rc != PTK_OK) return rc;
+    const size_t n = static_cast<size_t>(job->number_of_pixels);
+    if (n == 0) return PTK_OK;
+    DeviceBuffers tmp;
+    int32_t *d_obj, *d_prim;
+    double *d_dist, *d_pos, *d_nrm;
+    HIP_TRY(tmp.alloc(&d_obj, n));
+    HIP_TRY(tmp.alloc(&d_prim, n));
+    HIP_TRY(tmp.alloc(&d_dist, n));
+    HIP_TRY(tmp.alloc(&d_pos, 3 * n));
+    HIP_TRY(tmp.alloc(&d_nrm, 3 * n));
+    BatchParams b{};
+    b.start_idx = job->start_idx;
+    b.n_pixels = static_cast<uint32_t>(n);
+    b.n_samples = 1;
+    b.sample_offset = static_cast<uint32_t>(job->sample_offset);
+    b.n_paths = b.n_pixels;
+    b.seed = job->seed;
+    launch_primary(g_stream, s->dev, b, d_obj, d_prim, d_dist, d_pos, d_nrm);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    if (object_index) HIP_TRY(hipMemcpy(object_index, d_obj, n * 4, hipMemcpyDeviceToHost));
+    if (primitive_index) HIP_TRY(hipMemcpy(primitive_index, d_prim, n * 4, hipMemcpyDeviceToHost));
+    if (distance) HIP_TRY(hipMemcpy(distance, d_dist, n * 8, hipMemcpyDeviceToHost));
+    if (position) HIP_TRY(hipMemcpy(position, d_pos, n * 24, hipMemcpyDeviceToHost));
+    if (normal) HIP_TRY(hipMemcpy(normal, d_nrm, n * 24, hipMemcpyDeviceToHost));
+    return PTK_OK;
+}
+
+int ptk_trace_samples(PtkScene* s, const PtkRenderJob* job, double* color, double* position, double* normal) {
+    int rc = check_job(s, job, "ptk_trace_samples");
+    if (rc != PTK_OK) return rc;
+    const size_t total = static_cast<size_t>(job->number_of_pixels) * static_cast<size_t>(job->number_of_samples) * 3;
+    if (total == 0) return PTK_OK;
+    DeviceBuffers tmp;
+    double *d_color = nullptr, *d_pos = nullptr, *d_nrm = nullptr;
+    if (color) HIP_TRY(tmp.alloc(&d_color, total));
+    if (position) HIP_TRY(tmp.alloc(&d_pos, total));
+    if (normal) HIP_TRY(tmp.alloc(&d_nrm, total));
+    rc = for_each_batch(s, job, [&](const BatchParams& b, int64_t pixel_base) {
+        launch_gather_samples(g_stream, b, s->results, static_cast<size_t>(pixel_base), d_color, d_pos, d_nrm);
+        HIP_TRY(hipGetLastError());
+        return static_cast<int>(PTK_OK);
+    });
+    if (rc != PTK_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    if (color) HIP_TRY(hipMemcpy(color, d_color, total * 8, hipMemcpyDeviceToHost));
+    if (position) HIP_TRY(hipMemcpy(position, d_pos, total * 8, hipMemcpyDeviceToHost));
+    if (normal) HIP_TRY(hipMemcpy(normal, d_nrm, total * 8, hipMemcpyDeviceToHost));
+    return PTK_OK;
+}
+
+int ptk_film_create(int32_t width, int32_t height, PtkFilm** out) {
+    if (!out || width < 1 || height < 1) return fail(PTK_ERR_INVALID, "ptk_film_create: bad argument");
+    *out = nullptr;
+    if (require_init() != PTK_OK) return PTK_ERR_DEVICE;
+    std::unique_ptr<PtkFilm> f(new PtkFilm());
+    f->width = width;
+    f->height = height;
+    const size_t n = static_cast<size_t>(width) * static_cast<size_t>(height);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f->image), n * 24));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f->position), n * 24));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f->normal), n * 24));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f->counters), n * 8));
+    PtkFilm* film = f.release();
+    int rc = ptk_film_clear(film);
+    if (rc != PTK_OK) {
+        ptk_film_destroy(film);
+        return rc;
+    }
+    *out = film;
+    return PTK_OK;
+}
+
+void ptk_film_destroy(PtkFilm* f) {
+    if (!f) return;
+    if (g_stream) (void) hipStreamSynchronize(g_stream);
+    (void) hipFree(f->image);
+    (void) hipFree(f->position);
+    (void) hipFree(f->normal);
+    (void) hipFree(f->counters);
+    delete f;
+}
+
+int ptk_film_clear(PtkFilm* f) {
+    if (!f) return fail(PTK_ERR_INVALID, "ptk_film_clear: null film");
+    const size_t n = static_cast<size_t>(f->width) * static_cast<size_t>(f->height);
+    HIP_TRY(hipMemsetAsync(f->image, 0, n * 24, g_stream));
+    HIP_TRY(hipMemsetAsync(f->position, 0, n * 24, g_stream));
+    HIP_TRY(hipMemsetAsync(f->normal, 0, n * 24, g_stream));
+    HIP_TRY(hipMemsetAsync(f->counters, 0, n * 8, g_stream));
+    return PTK_OK;
+}
+
+int ptk_film_upload(PtkFilm* f, const double* image, const double* position, const double* normal, const uint64_t* counters) {
+    if (!f) return fail(PTK_ERR_INVALID, "ptk_film_upload: null film");
+    const size_t n = static_cast<size_t>(f->width) * static_cast<size_t>(f->height);
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    if (image) HIP_TRY(hipMemcpy(f->image, image, n * 24, hipMemcpyHostToDevice));
+    if (position) HIP_TRY(hipMemcpy(f->position, position, n * 24, hipMemcpyHostToDevice));
+    if (normal) HIP_TRY(hipMemcpy(f->normal, normal, n * 24, hipMemcpyHostToDevice));
+    if (counters) HIP_TRY(hipMemcpy(f->counters, counters, n * 8, hipMemcpyHostToDevice));
+    return PTK_OK;
+}
+
+int ptk_film_download(PtkFilm* f, double* image, double* position, double* normal, uint64_t* counters) {
+    if (!f) return fail(PTK_ERR_INVALID, "ptk_film_download: null film");
+    const size_t n = static_cast<size_t>(f->width) * static_cast<size_t>(f->height);
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    if (image) HIP_TRY(hipMemcpy(image, f->image, n * 24, hipMemcpyDeviceToHost));
+    if (position) HIP_TRY(hipMemcpy(position, f->position, n * 24, hipMemcpyDeviceToHost));
+    if (normal) HIP_TRY(hipMemcpy(normal, f->normal, n * 24, hipMemcpyDeviceToHost));
+    if (counters) HIP_TRY(hipMemcpy(counters, f->counters, n * 8, hipMemcpyDeviceToHost));
+    return PTK_OK;
+}
+
+int ptk_film_device_pointers(PtkFilm* f, double** image, double** position, double** normal, uint64_t** counters) {
+    if (!f) return fail(PTK_ERR_INVALID, "ptk_film_device_pointers: null film");
+    if (image) *image = f->image;
+    if (position) *position = f->position;
+    if (normal) *normal = f->normal;
+    if (counters) *counters = reinterpret_cast<uint64_t*>(f->counters);
+    return PTK_OK;
+}
+
+int ptk_render(PtkScene* s, PtkFilm* film, const PtkRenderJob* job) {
+    int rc = check_job(s, job, "ptk_render");
+    if (rc != PTK_OK) return rc;
+    if (!film || film->width != s->settings.width || film->height != s->settings.height)
+        return fail(PTK_ERR_INVALID, "ptk_render: film size does not match the scene");
+    return for_each_batch(s, job, [&](const BatchParams& b, int64_t) {
+        launch_accumulate(g_stream, b, s->results, film->image, film->position, film->normal, film->counters);
+        HIP_TRY(hipGetLastError());
+        s->stats.algorithmic_bytes += ACCUMULATE_BYTES_PER_PATH * b.n_paths;
+        return static_cast<int>(PTK_OK);
+    });
+}
+
+int ptk_render_host(PtkScene* s, const PtkRenderJob* job, double* image, double* position, double* normal, uint64_t* counters) {
+    int rc = check_job(s, job, "ptk_render_host");
+    if (rc != PTK_OK) return rc;
+    if (!image || !position || !normal || !counters) return fail(PTK_ERR_INVALID, "ptk_render_host: null buffer");
+    if (!s->host_film) {
+        rc = ptk_film_create(s->settings.width, s->settings.height, &s->host_film);
+        if (rc != PTK_OK) return rc;
+    }
+    PtkFilm* f = s->host_film;
+    const size_t first = static_cast<size_t>(job->start_idx), n = static_cast<size_t>(job->number_of_pixels);
+    if (n == 0) return PTK_OK;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpy(f->image + 3 * first, image + 3 * first, n * 24, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(f->position + 3 * first, position + 3 * first, n * 24, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(f->normal + 3 * first, normal + 3 * first, n * 24, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(f->counters + first, counters + first, n * 8, hipMemcpyHostToDevice));
+    rc = ptk_render(s, f, job);
+    if (rc != PTK_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpy(image + 3 * first, f->image + 3 * first, n * 24, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(position + 3 * first, f->position + 3 * first, n * 24, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(normal + 3 * first, f->normal + 3 * first, n * 24, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(counters + first, f->counters + first, n * 8, hipMemcpyDeviceToHost));
+    return PTK_OK;
+}
+
+int ptk_get_stats(PtkScene* s, PtkStats* stats) {
+    if (!s || !stats) return fail(PTK_ERR_INVALID, "ptk_get_stats: null argument");
+    *stats = s->stats;
+    return PTK_OK;
+}
+
+int ptk_reset_stats(PtkScene* s) {
+    if (!s) return fail(PTK_ERR_INVALID, "ptk_reset_stats: null argument");
+    s->stats = PtkStats{};
+    return PTK_OK;
+}
+
+// ---- denoise --------------------------------------------------------------------------------------
+int ptk_denoise_device(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t width, int32_t height, double* d_image,
+                       const double* d_position, const double* d_normal, double* d_scratch) {
+    if (require_init() != PTK_OK) return PTK_ERR_DEVICE;
+    if ((!tasks && n_tasks > 0) || width < 1 || height < 1 || !d_image || !d_position || !d_normal || !d_scratch)
+        return fail(PTK_ERR_INVALID, "ptk_denoise_device: bad argument");
+    const size_t bytes = static_cast<size_t>(width) * static_cast<size_t>(height) * 24;
+    double* src = d_image;
+    double* dst = d_scratch;
+    for (int32_t t = 0; t < n_tasks; t++) { // denoise() src/denoise.cpp:203-212
+        const PtkDenoiseTask& task = tasks[t];
+        if (task.mode == PTK_DENOISE_ATROUS) { // atrous_filter :135-147
+            double sigma_rt = task.sigma_rt, sigma_x = task.sigma_x, sigma_n = task.sigma_n;
+            int hole_width = 0;
+            for (int it = 0; it < task.iterations; it++) {
+                launch_atrous(g_stream, width, height, src, dst, d_position, d_normal, sigma_rt, sigma_x, sigma_n, hole_width);
+                HIP_TRY(hipGetLastError());
+                std::swap(src, dst);
+                sigma_rt /= 2.0;
+                sigma_x /= 2.0;
+                sigma_n /= 2.0;
+                hole_width += static_cast<int>(std::pow(2, it));
+            }
+        }
+        else if (task.mode == PTK_DENOISE_MEDIAN) {
+            if (task.kernel_size < 1 || task.kernel_size % 2 == 0 || task.kernel_size > 15)
+                return fail(PTK_ERR_INVALID, "ptk_denoise: median kernel_size must be odd and at most 15");
+            if (task.kernel_size > std::min(width, height))
+                return fail(PTK_ERR_INVALID, "Median filter kernel size is too large for this image size.");
+            launch_median(g_stream, width, height, src, dst, task.kernel_size, task.threshold);
+            HIP_TRY(hipGetLastError());
+            std::swap(src, dst);
+        }
+        else {
+            return fail(PTK_ERR_INVALID, "ptk_denoise: unknown mode");
+        }
+    }
+    if (src != d_image) HIP_TRY(hipMemcpyAsync(d_image, src, bytes, hipMemcpyDeviceToDevice, g_stream));
+    return PTK_OK;
+}
+
+int ptk_denoise(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t width, int32_t height, double* image,
+                const double* position, const double* normal) {
+    if (require_init() != PTK_OK) return PTK_ERR_DEVICE;
+    if ((!tasks && n_tasks > 0) || width < 1 || height < 1 || !image || !position || !normal)
+        return fail(PTK_ERR_INVALID, "ptk_denoise: bad argument");
+    const size_t n = static_cast<size_t>(width) * static_cast<size_t>(height) * 3;
+    DeviceBuffers tmp;
+    double *d_image, *d_pos, *d_nrm, *d_scratch;
+    HIP_TRY(tmp.alloc(&d_image, n));
+    HIP_TRY(tmp.alloc(&d_pos, n));
+    HIP_TRY(tmp.alloc(&d_nrm, n));
+    HIP_TRY(tmp.alloc(&d_scratch, n));
+    HIP_TRY(hipMemcpy(d_image, image, n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_pos, position, n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_nrm, normal, n * 8, hipMemcpyHostToDevice));
+    int rc = ptk_denoise_device(tasks, n_tasks, width, height, d_image, d_pos, d_nrm, d_scratch);
+    if (rc != PTK_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpy(image, d_image, n * 8, hipMemcpyDeviceToHost));
+    return PTK_OK;
+}
+
+} // extern "C"

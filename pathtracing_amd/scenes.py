@@ -1,0 +1,364 @@
+"""Scene-directory generators for tests and benchmarks.
+
+Each builder writes a directory in the reference's scene-directory layout (settings.json,
+scene.json, denoising.json; meshes and textures beside them) so that it can be given to
+`pathtracer <scene_directory>` unchanged.  The shipped scenes of the reference cannot travel to
+the GPU box, and its living-room assets are not in its repository at all, so the workloads named
+by the benchmark configuration are generated here:
+
+* ``cornell_example``   the Cornell box of the reference's scenes/example (same parameters)
+* ``material_zoo``      every material / object / light / camera feature in one small box
+* ``mesh_box``          Cornell walls + a procedurally generated OBJ mesh (up to millions of triangles)
+* ``cloud_box``         the Cornell box with a scattering-medium volume and coloured glass
+"""
+import json
+import os
+
+import numpy as np
+
+DEFAULT_DENOISING = {
+    "pipeline": [
+        {"mode": "median", "parameters": {"kernel_size": 3, "threshold": 0.5}},
+        {"mode": "atrous", "parameters": {"iterations": 4, "sigma_rt": 2, "sigma_x": 2, "sigma_n": 2}},
+    ]
+}
+
+
+def default_settings(**overrides):
+    s = {
+        "WIDTH": 1000, "HEIGHT": 1000, "samples_per_pixel": 100, "samples_per_iteration": 16,
+        "max_recursion_depth": 100, "min_recursion_steps": 3, "number_of_threads": 1,
+        "use_gamma_correction": True, "bvh_leaf_size": 4, "bvh_n_axis_splits": 16,
+        "enable_next_event_estimation": True, "enable_anti_aliasing": True,
+    }
+    s.update(overrides)
+    return s
+
+
+def _map3(name, rgb):
+    return {"name": name, "type": "ValueMap3D", "parameters": {"data": list(rgb)}}
+
+
+def _map1(name, value):
+    return {"name": name, "type": "ValueMap1D", "parameters": {"data": [value]}}
+
+
+def _map_file(name, kind, path):
+    return {"name": name, "type": kind, "parameters": {"file": path}}
+
+
+def _medium(name, subtype, scattering, absorption, ior, emission=(0, 0, 0)):
+    return {"name": name, "type": "Medium", "subtype": subtype,
+            "parameters": {"scattering_albedo": list(scattering), "absorption_albedo": list(absorption),
+                           "emission_coefficient": list(emission), "refractive_index": ior}}
+
+
+def _material(name, subtype, **parameters):
+    return {"name": name, "type": "Material", "subtype": subtype, "parameters": parameters}
+
+
+def _rect(name, position, v1, v2, L1, L2, material):
+    return {"name": name, "type": "Object", "subtype": "Rectangle",
+            "parameters": {"position": position, "v1": v1, "v2": v2, "L1": L1, "L2": L2, "material": material}}
+
+
+def _sphere(name, position, radius, material):
+    return {"name": name, "type": "Object", "subtype": "Sphere",
+            "parameters": {"material": material, "position": position, "radius": radius}}
+
+
+def _camera(position, X, Y, Z, width, focal, **dof):
+    cam = {"camera_position": position, "orientation": {"X": X, "Y": Y, "Z": Z}, "camera_width": width,
+           "focal_length": focal}
+    cam.update(dof)
+    return cam
+
+
+def _cornell_shell(wall_material="white_diffuse_material"):
+    """The six walls and the ceiling light of the example box (2.2 x 2 x 4 units)."""
+    return [
+        _rect("floor", [0, 0, 0], [1, 0, 0], [0, 0, -1], 2.2, 4, wall_material),
+        _rect("front_wall", [0, 1, -2], [1, 0, 0], [0, 1, 0], 2.2, 2, wall_material),
+        _rect("left_wall", [-1.1, 1, 0], [0, 0, -1], [0, 1, 0], 4, 2, "red_diffuse_material"),
+        _rect("right_wall", [1.1, 1, 0], [0, 0, 1], [0, 1, 0], 4, 2, "green_diffuse_material"),
+        _rect("back_wall", [0, 1, 2], [1, 0, 0], [0, -1, 0], 2.2, 2, wall_material),
+        _rect("roof", [0, 2, 0], [1, 0, 0], [0, 0, 1], 2.2, 4, wall_material),
+    ]
+
+
+_LIGHT = _rect("light_source", [0, 1.9999, -1], [1, 0, 0], [0, 0, 1], 0.4, 0.4, "light_source_material")
+
+_BASE_MAPS = [_map3("red", [0.8, 0, 0]), _map3("green", [0, 0.6, 0]), _map3("blue", [0, 0, 0.8]),
+              _map3("cyan", [0, 0.6, 0.8]), _map3("gold", [1.0, 0.84, 0.05]), _map3("white", [1, 1, 1]),
+              _map1("gold_roughness", 0.2), _map1("glass_roughness", 0.15), _map1("light_strength", 40)]
+
+_BASE_MEDIA = [_medium("air_medium", "BeersLawMedium", [0, 0, 0], [0, 0, 0], 1.0),
+               _medium("glass_medium", "BeersLawMedium", [0, 0, 0], [0, 0, 0], 1.5),
+               _medium("cyan_glass_medium", "BeersLawMedium", [0, 0, 0], [10, 2, 2], 1.5)]
+
+_BASE_MATERIALS = [
+    _material("red_diffuse_material", "Diffuse", albedo_map="red"),
+    _material("green_diffuse_material", "Diffuse", albedo_map="green"),
+    _material("blue_diffuse_material", "Diffuse", albedo_map="blue", surface_refractive_index=1.5),
+    _material("cyan_glass_material", "Transparent", albedo_map="cyan", surface_refractive_index=1.5,
+              internal_medium="cyan_glass_medium", external_medium="air_medium"),
+    _material("gold_material", "MetallicMicrofacet", albedo_map="gold", surface_refractive_index=0.3,
+              extinction_coefficient=2.9, roughness_map="gold_roughness"),
+    _material("rough_glass_material", "TransparentMicrofacet", roughness_map="glass_roughness",
+              internal_medium="glass_medium", external_medium="air_medium", surface_refractive_index=1.5),
+    _material("mirror_material", "ReflectiveMicrofacet", albedo_map="white", surface_refractive_index=1.5),
+    _material("white_diffuse_material", "Diffuse", albedo_map="white"),
+    _material("light_source_material", "Diffuse", albedo_map="white", emission_color_map="white",
+              light_intensity_map="light_strength", is_light_source=True),
+]
+
+_EXAMPLE_CAMERA = _camera([0, 0.9, 1.9], 90, 0, 0, 0.036, 0.036)
+
+
+def cornell_example_dict():
+    objects = _cornell_shell() + [
+        _sphere("blue_ball", [-0.35, 0.5, -1.3], 0.5, "blue_diffuse_material"),
+        _sphere("glass_ball", [-0.5, 0.1, -0.5], 0.1, "cyan_glass_material"),
+        _sphere("rough_glass_ball", [0, 0.25, -0.4], 0.25, "rough_glass_material"),
+        _sphere("mirror_ball", [0.4, 0.15, -0.5], 0.15, "mirror_material"),
+        _sphere("gold_ball", [0.5, 0.25, -1], 0.25, "gold_material"),
+        _LIGHT,
+    ]
+    return {"valuemaps": list(_BASE_MAPS), "media": list(_BASE_MEDIA), "materials": list(_BASE_MATERIALS),
+            "objects": objects, "background_medium": "air_medium", "background_color": [0.0, 0.0, 0.0],
+            "camera": dict(_EXAMPLE_CAMERA)}
+
+
+def write_scene_directory(directory, scene, settings=None, denoising=None):
+    os.makedirs(directory, exist_ok=True)
+    with open(os.path.join(directory, "scene.json"), "w") as f:
+        json.dump(scene, f, indent=1)
+    with open(os.path.join(directory, "settings.json"), "w") as f:
+        json.dump(settings or default_settings(), f, indent=1)
+    with open(os.path.join(directory, "denoising.json"), "w") as f:
+        json.dump(denoising or DEFAULT_DENOISING, f, indent=1)
+    return directory
+
+
+def cornell_example(directory, **settings):
+    """The benchmark's first workload: the reference's example Cornell box (12 analytic objects)."""
+    return write_scene_directory(directory, cornell_example_dict(), default_settings(**settings))
+
+
+# ------------------------------------------------------------------------------------------
+# textures and meshes
+# ------------------------------------------------------------------------------------------
+def write_map_file(path, data):
+    """`.map`: float64 [width, height, dim, data...] with data row-major [h][w][dim]."""
+    a = np.ascontiguousarray(data, dtype=np.float64)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    h, w, d = a.shape
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    np.concatenate([np.array([w, h, d], dtype=np.float64), a.ravel()]).tofile(path)
+
+
+def value_noise(width, height, channels, seed, cells=8):
+    """Smooth tileable value noise in [0, 1], [height, width, channels]."""
+    rng = np.random.default_rng(seed)
+    grid = rng.random((cells, cells, channels))
+    ys = np.arange(height) * cells / height
+    xs = np.arange(width) * cells / width
+    y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+    fy, fx = (ys - y0)[:, None, None], (xs - x0)[None, :, None]
+    fy, fx = fy * fy * (3 - 2 * fy), fx * fx * (3 - 2 * fx)
+    y1, x1 = (y0 + 1) % cells, (x0 + 1) % cells
+    a, b = grid[y0][:, x0], grid[y0][:, x1]
+    c, d = grid[y1][:, x0], grid[y1][:, x1]
+    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+
+
+def checker(width, height, cells, low, high):
+    y, x = np.mgrid[0:height, 0:width]
+    mask = ((x * cells // width) + (y * cells // height)) % 2
+    return np.where(mask, high, low).astype(np.float64)
+
+
+def write_bumpy_sphere_obj(path, n_lon, n_lat, seed=7, bump=0.08, quads=True):
+    """UV sphere with a sinusoidal + seeded-noise radial displacement, written in the OBJ subset
+    the loader accepts (single spaces; `v`, `vt`, `vn`, `f a/b/c`).  Triangles: 2*n_lon*(n_lat-1).
+    n_lon=1024, n_lat=513 gives exactly 1,048,576."""
+    rng = np.random.default_rng(seed)
+    theta = np.linspace(0.0, np.pi, n_lat + 1)           # rows of vertices, poles included
+    phi = np.linspace(0.0, 2 * np.pi, n_lon + 1)         # seam duplicated for clean UVs
+    T, P = np.meshgrid(theta, phi, indexing="ij")
+    noise = rng.random((n_lat + 1, n_lon + 1)) * 0.25
+    noise[:, -1] = noise[:, 0]
+    r = 1.0 + bump * (np.sin(5 * T) * np.sin(4 * P) + noise * np.sin(T))
+    x, y, z = r * np.sin(T) * np.cos(P), r * np.cos(T), r * np.sin(T) * np.sin(P)
+    nx, ny, nz = np.sin(T) * np.cos(P), np.cos(T), np.sin(T) * np.sin(P)
+    u, v = P / (2 * np.pi), 1.0 - T / np.pi
+    cols = n_lon + 1
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "w") as f:
+        f.write("# generated bumpy sphere\n")
+        f.write("".join("v %.9g %.9g %.9g\n" % t for t in zip(x.ravel(), y.ravel(), z.ravel())))
+        f.write("".join("vt %.9g %.9g\n" % t for t in zip(u.ravel(), v.ravel())))
+        f.write("".join("vn %.9g %.9g %.9g\n" % t for t in zip(nx.ravel(), ny.ravel(), nz.ravel())))
+        i, j = np.meshgrid(np.arange(n_lat), np.arange(n_lon), indexing="ij")
+        a = (i * cols + j + 1).ravel()
+        b = (i * cols + j + 2).ravel()
+        c = ((i + 1) * cols + j + 2).ravel()
+        d = ((i + 1) * cols + j + 1).ravel()
+        rows = i.ravel()
+        lines = []
+        for k in range(a.size):
+            A, B, Cc, D = a[k], b[k], c[k], d[k]
+            if rows[k] == 0:               # north-pole fan: one triangle
+                lines.append("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (A, A, A, Cc, Cc, Cc, D, D, D))
+            elif rows[k] == n_lat - 1:     # south-pole fan
+                lines.append("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (A, A, A, B, B, B, D, D, D))
+            elif quads:
+                lines.append("f %d/%d/%d %d/%d/%d %d/%d/%d %d/%d/%d\n" % (A, A, A, B, B, B, Cc, Cc, Cc, D, D, D))
+            else:
+                lines.append("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (A, A, A, B, B, B, Cc, Cc, Cc))
+                lines.append("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (A, A, A, Cc, Cc, Cc, D, D, D))
+            if len(lines) >= 65536:
+                f.write("".join(lines))
+                lines = []
+        f.write("".join(lines))
+    return 2 * n_lon * (n_lat - 1)
+
+
+def mesh_box(directory, n_lon=64, n_lat=33, material="gold", smooth=True, textured=False, seed=7, **settings):
+    """Cornell walls + ceiling light + one OBJ mesh placed with center/size/orientation.
+    `material`: 'gold' (MetallicMicrofacet a=0.2), 'rough_glass' (TransparentMicrofacet),
+    'glass' (Transparent, IOR 1.5) or 'diffuse'."""
+    os.makedirs(directory, exist_ok=True)
+    obj_path = os.path.join(directory, "models", "bumpy_sphere.obj")
+    n_tri = write_bumpy_sphere_obj(obj_path, n_lon, n_lat, seed=seed)
+    maps = list(_BASE_MAPS)
+    materials = list(_BASE_MATERIALS)
+    if textured:
+        tex = value_noise(256, 256, 3, seed=11)
+        write_map_file(os.path.join(directory, "maps", "noise_albedo.map"), tex)
+        write_map_file(os.path.join(directory, "maps", "checker_roughness.map"), checker(128, 128, 16, 0.05, 0.4))
+        maps += [_map_file("noise_albedo", "ValueMap3D", "maps/noise_albedo.map"),
+                 _map_file("checker_roughness", "ValueMap1D", "maps/checker_roughness.map")]
+        materials += [_material("textured_material", "Glossy", albedo_map="noise_albedo",
+                                surface_refractive_index=1.3, roughness_map="checker_roughness")]
+    materials += [_material("glass_material", "Transparent", internal_medium="glass_medium",
+                            external_medium="air_medium"),
+                  _material("mesh_diffuse_material", "Diffuse", albedo_map="blue")]
+    name = {"gold": "gold_material", "rough_glass": "rough_glass_material", "glass": "glass_material",
+            "diffuse": "mesh_diffuse_material", "textured": "textured_material"}[material if not textured else "textured"]
+    mesh = {"name": "mesh", "type": "Object", "subtype": "ObjectUnion",
+            "parameters": {"file": "models/bumpy_sphere.obj", "material": name, "enable_smooth_shading": bool(smooth),
+                           "center": [0.0, 0.62, -0.8], "size": 0.6, "orientation": {"X": 20, "Y": 35, "Z": 10}}}
+    scene = {"valuemaps": maps, "media": list(_BASE_MEDIA), "materials": materials,
+             "objects": _cornell_shell() + [mesh, _LIGHT], "background_medium": "air_medium",
+             "background_color": [0.0, 0.0, 0.0], "camera": dict(_EXAMPLE_CAMERA)}
+    write_scene_directory(directory, scene, default_settings(**settings))
+    return n_tri
+
+
+def material_zoo(directory, dof=None, **settings):
+    """One small box exercising every material, object, light and texture path:
+    Plane floor, top-level Triangle, Glossy / Reflective / Transparent / all microfacet types,
+    a transparency-mapped (cut-out) rectangle, file textures, a sphere light and a rectangle light,
+    a non-black background, and optionally a thin-lens camera (dof='circle'|'square')."""
+    os.makedirs(directory, exist_ok=True)
+    write_map_file(os.path.join(directory, "maps", "zoo_albedo.map"), value_noise(64, 32, 3, seed=3))
+    write_map_file(os.path.join(directory, "maps", "zoo_cutout.map"), checker(32, 32, 8, 0.0, 1.0))
+    write_map_file(os.path.join(directory, "maps", "zoo_rough.map"), 0.05 + 0.3 * value_noise(32, 32, 1, seed=5)[:, :, 0])
+    maps = list(_BASE_MAPS) + [
+        _map_file("zoo_albedo", "ValueMap3D", "maps/zoo_albedo.map"),
+        _map_file("zoo_cutout", "ValueMap1D", "maps/zoo_cutout.map"),
+        _map_file("zoo_rough", "ValueMap1D", "maps/zoo_rough.map"),
+        _map1("half", 0.5), _map1("sphere_light_strength", 25), _map3("warm", [0.9922, 0.9569, 0.8627]),
+        _map1("wood_roughness", 0.3),
+    ]
+    materials = list(_BASE_MATERIALS) + [
+        _material("glossy_material", "Glossy", albedo_map="zoo_albedo", surface_refractive_index=1.3,
+                  roughness_map="wood_roughness"),
+        _material("glossy_metal_material", "Glossy", albedo_map="gold", surface_refractive_index=1.8,
+                  roughness_map="zoo_rough", is_dielectric=False),
+        _material("perfect_mirror_material", "Reflective", albedo_map="cyan", is_dielectric=False),
+        _material("dielectric_mirror_material", "Reflective"),
+        _material("clear_glass_material", "Transparent", internal_medium="glass_medium", external_medium="air_medium"),
+        _material("cutout_material", "Diffuse", albedo_map="green", transparency_map="zoo_cutout"),
+        _material("veil_material", "ReflectiveMicrofacet", albedo_map="white", roughness_map="gold_roughness",
+                  transparency_map="half"),
+        _material("textured_diffuse_material", "Diffuse", albedo_map="zoo_albedo"),
+        _material("sphere_light_material", "Diffuse", albedo_map="white", emission_color_map="warm",
+                  light_intensity_map="sphere_light_strength", is_light_source=True),
+    ]
+    objects = [
+        {"name": "ground", "type": "Object", "subtype": "Plane",
+         "parameters": {"position": [0, 0, 0], "v1": [2, 0, 0], "v2": [0, 0, -3], "material": "textured_diffuse_material"}},
+        _rect("front_wall", [0, 1, -2], [1, 0, 0], [0, 1, 0], 2.2, 2, "white_diffuse_material"),
+        _rect("left_wall", [-1.1, 1, 0], [0, 0, -1], [0, 1, 0], 4, 2, "red_diffuse_material"),
+        _rect("right_wall", [1.1, 1, 0], [0, 0, 1], [0, 1, 0], 4, 2, "glossy_material"),
+        _rect("roof", [0, 2, 0], [1, 0, 0], [0, 0, 1], 2.2, 4, "white_diffuse_material"),
+        _sphere("glossy_ball", [-0.6, 0.3, -1.0], 0.3, "glossy_material"),
+        _sphere("glossy_metal_ball", [0.65, 0.2, -0.2], 0.2, "glossy_metal_material"),
+        _sphere("mirror_ball", [0.55, 0.3, -1.2], 0.3, "perfect_mirror_material"),
+        _sphere("dielectric_mirror_ball", [-0.75, 0.15, -0.1], 0.15, "dielectric_mirror_material"),
+        _sphere("clear_glass_ball", [0.0, 0.25, -0.6], 0.25, "clear_glass_material"),
+        _sphere("cyan_glass_ball", [-0.3, 0.12, 0.2], 0.12, "cyan_glass_material"),
+        _sphere("rough_glass_ball", [0.3, 0.15, 0.1], 0.15, "rough_glass_material"),
+        _sphere("gold_ball", [-0.1, 0.2, -1.5], 0.2, "gold_material"),
+        _sphere("veil_ball", [0.2, 0.75, -1.1], 0.18, "veil_material"),
+        _rect("cutout_screen", [-0.3, 0.6, -0.2], [1, 0, 0.3], [0, 1, 0], 0.6, 0.6, "cutout_material"),
+        {"name": "lone_triangle", "type": "Object", "subtype": "Triangle",
+         "parameters": {"p1": [-1.0, 0.05, -1.8], "p2": [-0.2, 0.05, -1.9], "p3": [-0.6, 0.9, -1.7],
+                        "material": "gold_material"}},
+        _sphere("sphere_light", [-0.6, 1.6, -0.6], 0.12, "sphere_light_material"),
+        _rect("light_source", [0.4, 1.9999, -1], [1, 0, 0], [0, 0, 1], 0.4, 0.4, "light_source_material"),
+    ]
+    camera = _camera([0, 0.9, 1.9], 88, 3, 0, 0.036, 0.036)
+    if dof:
+        camera.update({"depth_of_field_mode": dof, "focus_distance": 2.6, "aperture_size": 0.08})
+    scene = {"valuemaps": maps, "media": list(_BASE_MEDIA), "materials": materials, "objects": objects,
+             "background_medium": "air_medium", "background_color": [0.05, 0.07, 0.1], "camera": camera}
+    return write_scene_directory(directory, scene, default_settings(**settings))
+
+
+def cloud_box(directory, fog=False, **settings):
+    """The example box plus a homogeneous scattering volume bounded by an index-matched transparent
+    sphere (which next-event estimation passes through), an emissive absorbing volume, and the
+    coloured Beer's-law glass ball.  `fog=True` additionally makes the background medium scatter."""
+    media = list(_BASE_MEDIA) + [
+        _medium("cloud_medium", "HomogenousScatteringMedium", [2, 2, 2], [0.05, 0.05, 0.05], 1.0),
+        _medium("ember_medium", "HomogenousScatteringMedium", [0.5, 0.2, 0.1], [1.0, 2.0, 3.0], 1.0,
+                emission=[3.0, 1.0, 0.2]),
+        _medium("fog_medium", "HomogenousScatteringMedium", [0.08, 0.08, 0.1], [0.01, 0.01, 0.0], 1.0),
+    ]
+    materials = list(_BASE_MATERIALS) + [
+        _material("cloud_boundary_material", "Transparent", internal_medium="cloud_medium",
+                  external_medium="fog_medium" if fog else "air_medium"),
+        _material("ember_boundary_material", "Transparent", internal_medium="ember_medium",
+                  external_medium="fog_medium" if fog else "air_medium"),
+    ]
+    objects = _cornell_shell() + [
+        _sphere("blue_ball", [-0.35, 0.5, -1.3], 0.5, "blue_diffuse_material"),
+        _sphere("glass_ball", [-0.5, 0.1, -0.5], 0.1, "cyan_glass_material"),
+        _sphere("cloud", [0.35, 0.45, -0.6], 0.4, "cloud_boundary_material"),
+        _sphere("ember", [-0.6, 0.2, 0.1], 0.2, "ember_boundary_material"),
+        _sphere("gold_ball", [0.5, 0.25, -1.4], 0.25, "gold_material"),
+        _LIGHT,
+    ]
+    scene = {"valuemaps": list(_BASE_MAPS), "media": media, "materials": materials, "objects": objects,
+             "background_medium": "fog_medium" if fog else "air_medium", "background_color": [0.0, 0.0, 0.0],
+             "camera": dict(_EXAMPLE_CAMERA)}
+    return write_scene_directory(directory, scene, default_settings(**settings))
+
+
+def emissive_mesh_box(directory, **settings):
+    """Cornell walls lit only by a small emissive OBJ mesh (area-sampled triangle light)."""
+    os.makedirs(directory, exist_ok=True)
+    write_bumpy_sphere_obj(os.path.join(directory, "models", "lamp.obj"), 8, 5, seed=2, bump=0.2)
+    materials = list(_BASE_MATERIALS)
+    lamp = {"name": "lamp", "type": "Object", "subtype": "ObjectUnion",
+            "parameters": {"file": "models/lamp.obj", "material": "light_source_material",
+                           "center": [0.0, 1.5, -1.0], "size": 0.25}}
+    objects = _cornell_shell() + [_sphere("blue_ball", [-0.35, 0.5, -1.3], 0.5, "blue_diffuse_material"),
+                                  _sphere("gold_ball", [0.5, 0.25, -1], 0.25, "gold_material"), lamp]
+    scene = {"valuemaps": list(_BASE_MAPS), "media": list(_BASE_MEDIA), "materials": materials, "objects": objects,
+             "background_medium": "air_medium", "background_color": [0.0, 0.0, 0.0], "camera": dict(_EXAMPLE_CAMERA)}
+    return write_scene_directory(directory, scene, default_settings(**settings))

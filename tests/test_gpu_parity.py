@@ -1,0 +1,152 @@
+"""GPU parity: the HIP library (through its C ABI) against the CPU oracle on the same scenes and the
+same counter-based random streams.  Tolerances: ids bit-exact except where a ray grazes an edge
+(>= 99.99 % agreement required); fp64 radiance per sample within 1e-9 relative for >= 99.9 % of the
+samples (device libm and fused multiply-adds differ from the host's in the last bits, and a path
+whose discrete decision sits within that noise takes another branch), image means within 1e-6."""
+import numpy as np
+import pytest
+
+import pathtracing_amd as pt
+
+pytestmark = pytest.mark.gpu
+
+SCENES = ["example", "zoo", "zoo_circle", "zoo_square", "mesh_gold", "mesh_rough_glass", "mesh_glass",
+          "mesh_textured", "cloud", "fog", "lamp"]
+
+
+@pytest.fixture(scope="module")
+def ob():
+    from oracle import binding
+    return binding
+
+
+@pytest.fixture(scope="module", autouse=True)
+def gpu():
+    pt.init(0)
+
+
+def _close_fraction(a, b, rtol=1e-9, atol=1e-12):
+    ok = np.isclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
+    return ok.reshape(ok.shape[0], -1).all(axis=1).mean()
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_primary_hits_match_oracle(scene_dirs, ob, name):
+    hs = pt.load_scene_directory(scene_dirs[name], enable_anti_aliasing=0)
+    n = hs.settings.width * hs.settings.height
+    job = pt.make_job(0, n, 1, 0, 3)
+    want = ob.OracleScene(hs).trace_primary(job)
+    got = pt.DeviceScene(hs).trace_primary(job)
+    same = (want[0] == got[0]) & (want[1] == got[1])
+    assert same.mean() >= 0.9999, f"id agreement {same.mean()}"
+    hit = same & (want[0] >= 0)
+    np.testing.assert_allclose(got[2][hit], want[2][hit], rtol=1e-11)
+    np.testing.assert_allclose(got[3][hit], want[3][hit], rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(got[4][hit], want[4][hit], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_samples_match_oracle(scene_dirs, ob, name):
+    hs = pt.load_scene_directory(scene_dirs[name])
+    n = hs.settings.width * hs.settings.height
+    job = pt.make_job(0, n, 6, 2, 12345)
+    want = ob.OracleScene(hs).trace_samples(job)
+    got = pt.DeviceScene(hs).trace_samples(job)
+    for w, g, what in zip(want, got, ("radiance", "position", "normal")):
+        w2, g2 = w.reshape(-1, 3), g.reshape(-1, 3)
+        frac = _close_fraction(g2, w2)
+        assert frac >= 0.999, f"{name} {what}: only {frac:.5f} of the samples agree"
+    mean_w, mean_g = want[0].mean(axis=(0, 1)), got[0].mean(axis=(0, 1))
+    np.testing.assert_allclose(mean_g, mean_w, rtol=2e-3)
+
+
+def test_results_do_not_depend_on_batch_size(scene_dirs):
+    hs = pt.load_scene_directory(scene_dirs["example"])
+    n = hs.settings.width * hs.settings.height
+    job = pt.make_job(0, n, 4, 0, 7)
+    whole = pt.DeviceScene(hs).trace_samples(job)
+    pieces = pt.DeviceScene(hs, max_paths_in_flight=1000).trace_samples(job)
+    for a, b in zip(whole, pieces):
+        assert np.array_equal(a, b)
+
+
+def test_pixel_subrange_equals_full_frame(scene_dirs):
+    hs = pt.load_scene_directory(scene_dirs["zoo"])
+    n = hs.settings.width * hs.settings.height
+    dev = pt.DeviceScene(hs)
+    full = dev.trace_samples(pt.make_job(0, n, 3, 5, 99))[0]
+    part = dev.trace_samples(pt.make_job(1000, 500, 3, 5, 99))[0]
+    assert np.array_equal(full[1000:1500], part)
+
+
+def test_film_running_mean_matches_oracle(scene_dirs, ob):
+    hs = pt.load_scene_directory(scene_dirs["example"])
+    W, H = hs.settings.width, hs.settings.height
+    n = W * H
+    dev = pt.DeviceScene(hs)
+    film = pt.Film(W, H)
+    osc = ob.OracleScene(hs)
+    img, pos, nrm = np.zeros((H, W, 3)), np.zeros((H, W, 3)), np.zeros((H, W, 3))
+    cnt = np.zeros((H, W), dtype=np.uint64)
+    for start, count, spp, offset in [(0, n, 4, 0), (0, n // 2, 3, 4), (n // 2, n - n // 2, 5, 4)]:
+        job = pt.make_job(start, count, spp, offset, 21)
+        dev.render(film, job)
+        osc.render(job, img, pos, nrm, cnt, threads=4)
+    g_img, g_pos, g_nrm, g_cnt = film.download()
+    assert np.array_equal(g_cnt, cnt)
+    assert _close_fraction(g_img.reshape(-1, 3), img.reshape(-1, 3), rtol=1e-9) >= 0.99
+    np.testing.assert_allclose(g_img.mean(), img.mean(), rtol=1e-4)
+    np.testing.assert_allclose(g_pos, pos, rtol=1e-9, atol=1e-9)
+    assert _close_fraction(g_nrm.reshape(-1, 3), nrm.reshape(-1, 3), rtol=1e-8, atol=1e-10) >= 0.999
+
+
+def test_render_host_updates_caller_buffers(scene_dirs):
+    hs = pt.load_scene_directory(scene_dirs["example"])
+    W, H = hs.settings.width, hs.settings.height
+    n = W * H
+    dev = pt.DeviceScene(hs)
+    film = pt.Film(W, H)
+    img, pos, nrm = np.zeros((H, W, 3)), np.zeros((H, W, 3)), np.zeros((H, W, 3))
+    cnt = np.zeros((H, W), dtype=np.uint64)
+    for start, count in [(0, 1500), (1500, n - 1500)]:
+        job = pt.make_job(start, count, 2, 0, 5)
+        dev.render_host(job, img, pos, nrm, cnt)
+        dev.render(film, job)
+    g = film.download()
+    assert np.array_equal(g[0], img) and np.array_equal(g[1], pos) and np.array_equal(g[2], nrm)
+    assert np.array_equal(g[3], cnt) and cnt.min() == 2
+
+
+def test_denoise_matches_oracle(scene_dirs, ob):
+    hs = pt.load_scene_directory(scene_dirs["example"])
+    W, H = hs.settings.width, hs.settings.height
+    dev = pt.DeviceScene(hs)
+    film = pt.Film(W, H)
+    dev.render(film, pt.make_job(0, W * H, 8, 0, 1))
+    img, pos, nrm, _ = film.download()
+    for pipeline in ([{"mode": "median", "kernel_size": 3, "threshold": 0.5},
+                      {"mode": "atrous", "iterations": 4, "sigma_rt": 2, "sigma_x": 2, "sigma_n": 2}],
+                     [{"mode": "atrous", "iterations": 2, "sigma_rt": 0.7, "sigma_x": 1.5, "sigma_n": 0.4}],
+                     [{"mode": "median", "kernel_size": 5, "threshold": 0.05}],
+                     [{"mode": "median", "kernel_size": 7, "threshold": 0.0}]):
+        tasks = pt.make_denoise_tasks(pipeline)
+        want = ob.oracle_denoise(tasks, img, pos, nrm)
+        got = pt.denoise(tasks, img, pos, nrm)
+        np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-13)
+
+
+def test_statistics_count_paths_and_rays(scene_dirs, ob):
+    hs = pt.load_scene_directory(scene_dirs["example"])
+    n = hs.settings.width * hs.settings.height
+    job = pt.make_job(0, n, 4, 0, 3)
+    dev = pt.DeviceScene(hs)
+    dev.trace_samples(job)
+    osc = ob.OracleScene(hs)
+    osc.trace_samples(job)
+    s, o = dev.stats(), osc.stats()
+    assert s.paths == o.paths == n * 4
+    assert abs(int(s.extension_rays) - int(o.extension_rays)) <= 0.001 * o.extension_rays
+    # the GPU does not march connections that face away from the surface (they contribute nothing);
+    # the reference marches them before discarding them
+    assert 0.85 * o.shadow_rays <= s.shadow_rays <= o.shadow_rays
+    assert s.algorithmic_bytes > 0
