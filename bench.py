@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric: Mpaths/s (whole job).  A path is one camera sample (one `raytrace` call of the reference,
+app/pathtracer.cpp:39).  A step renders `--spp-per-step` samples of every pixel of the frame and
+folds them into the device-resident film; scene, path pools and film are in HBM before the timed
+region starts.  At N > 1 (launched by torch.distributed.run, one rank per GPU) every rank renders
+its own slice of sample indices of the whole frame -- per-GPU work fixed, weak scaling -- and the
+films are summed over RCCL once at the end of the timed region.
+
+Workloads (`--workload`):
+  example   the reference's scenes/example Cornell box at 1920x1080 (benchmark configuration 2)
+  mesh      Cornell walls + a generated 1,048,576-triangle OBJ mesh at 1920x1080
+  cloud     scattering-medium + coloured-glass scene at 1920x1080, with the denoise pass timed apart
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="example", choices=["example", "mesh", "cloud"])
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--mesh-lon", type=int, default=1024)
+    ap.add_argument("--mesh-lat", type=int, default=513)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+def build_workload(args, directory):
+    from pathtracing_amd import scenes
+    settings = dict(WIDTH=args.width, HEIGHT=args.height, samples_per_pixel=args.spp_per_step * args.steps,
+                    samples_per_iteration=args.spp_per_step)
+    if args.workload == "example":
+        scenes.cornell_example(directory, **settings)
+        return "scenes/example Cornell box (12 analytic objects)"
+    if args.workload == "mesh":
+        n = scenes.mesh_box(directory, n_lon=args.mesh_lon, n_lat=args.mesh_lat, material="gold", smooth=True, **settings)
+        return f"Cornell walls + generated {n}-triangle OBJ mesh (MetallicMicrofacet)"
+    scenes.cloud_box(directory, **settings)
+    return "Cornell box + homogeneous scattering cloud + coloured glass"
+
+
+def cpu_baseline(host_scene, args, threads):
+    """The CPU restatement (oracle/) on this box's host cores, on a bounded sample of the same frame."""
+    from oracle import binding as ob
+    import pathtracing_amd as pt
+    W, H = args.width, args.height
+    osc = ob.OracleScene(host_scene)
+    image, pos, nrm = np.zeros((H, W, 3)), np.zeros((H, W, 3)), np.zeros((H, W, 3))
+    cnt = np.zeros((H, W), dtype=np.uint64)
+    # calibrate on a thin slice, then size the sample for roughly 15 s
+    rows = max(1, H // 135)
+    job = pt.make_job(0, rows * W, 1, 0, args.seed)
+    t0 = time.perf_counter()
+    osc.render(job, image, pos, nrm, cnt, threads=threads)
+    rate = rows * W / max(time.perf_counter() - t0, 1e-9)
+    spp = int(max(1, min(8, rate * 15.0 / (W * H))))
+    n_pixels = W * H if rate * 15.0 >= W * H else int(max(W, (rate * 15.0) // W * W))
+    job = pt.make_job(0, n_pixels, spp, 1, args.seed)
+    t0 = time.perf_counter()
+    osc.render(job, image, pos, nrm, cnt, threads=threads)
+    dt = time.perf_counter() - t0
+    paths = n_pixels * spp
+    return {"value": paths / dt / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
+            "sample": f"{n_pixels} pixels x {spp} spp of the same {W}x{H} frame ({paths} paths, {dt:.1f} s), "
+                      "fp64 CPU restatement of the reference with the same counter-based random streams"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    import pathtracing_amd as pt
+
+    pt.init(local_rank)
+    tmp = tempfile.mkdtemp(prefix=f"ptk_bench_r{rank}_")
+    workload_name = build_workload(args, tmp)
+    t_build = time.perf_counter()
+    host_scene = pt.load_scene_directory(tmp)
+    W, H = args.width, args.height
+    n_pixels = W * H
+    spp = args.spp_per_step
+    scene = pt.DeviceScene(host_scene, max_paths_in_flight=max(n_pixels * spp, 1 << 22))
+    build_s = time.perf_counter() - t_build
+
+    if distributed:
+        import torch
+        dev = torch.device("cuda", local_rank)
+        t_img = torch.zeros(n_pixels * 3, dtype=torch.float64, device=dev)
+        t_pos = torch.zeros(n_pixels * 3, dtype=torch.float64, device=dev)
+        t_nrm = torch.zeros(n_pixels * 3, dtype=torch.float64, device=dev)
+        t_cnt = torch.zeros(n_pixels, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        film = pt.Film(W, H, device_buffers=(t_img.data_ptr(), t_pos.data_ptr(), t_nrm.data_ptr(), t_cnt.data_ptr()))
+    else:
+        film = pt.Film(W, H)
+
+    def barrier():
+        pt.sync()
+        if distributed:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # every rank owns a disjoint slice of sample indices (weak scaling: the slice length is fixed)
+    from pathtracing_amd.distributed import combine_films, sample_slice
+    total_spp = spp * (args.warmup + args.steps)
+    offset, _ = sample_slice(rank, world, total_spp * world)
+
+    def step(i):
+        scene.render(film, pt.make_job(0, n_pixels, spp, offset + i * spp, args.seed))
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    film.clear()
+    scene.reset_stats()
+    pt.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    pt.sync()
+    if distributed:
+        import torch
+        # combine the per-GPU sample slices: weighted mean over RCCL, once per flush
+        combine_films(t_img, t_pos, t_nrm, t_cnt)
+        torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    pt.set_profiling(False)
+    if distributed:
+        import torch
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    st = scene.stats()
+    paths_per_rank = n_pixels * spp * args.steps
+    total_paths = paths_per_rank * world
+    value = total_paths / elapsed / 1e6
+
+    # dominant kernel family by device time (HIP events on the library's stream, this timed region)
+    families = {
+        "k_extend": (st.extend_ms, st.extend_bytes, st.extend_launches),
+        "k_shade": (st.shade_ms, st.shade_bytes, st.shade_launches),
+        "k_connect": (st.connect_ms, st.connect_bytes, st.connect_launches),
+    }
+    dominant = max(families, key=lambda k: families[k][0])
+    d_ms, d_bytes, d_launches = families[dominant]
+    achieved = (d_bytes / max(d_launches, 1)) / (d_ms / max(d_launches, 1) * 1e-3) / 1e9 if d_ms > 0 else 0.0
+    traffic = None
+    traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(traffic_file):
+        try:
+            with open(traffic_file) as f:
+                traffic = json.load(f).get(args.workload, {}).get(dominant)
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "bytes_per_launch": d_bytes / max(d_launches, 1), "ms_per_launch": d_ms / max(d_launches, 1),
+                "launches": int(d_launches),
+                "device_ms": {k: v[0] for k, v in families.items()}}
+
+    out = {
+        "metric": "Mpaths/s (whole node) at 1080p, scenes/example + 1M-tri mesh, 1/2/4/8 GPUs",
+        "value": value, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{workload_name}, {W}x{H}, {spp} spp per step ({spp * args.steps} spp in the timed region)",
+                   "paths_per_step_per_gpu": n_pixels * spp, "partition": "sample-index slices per GPU, film all-reduce at the end",
+                   "scene_build_s": build_s},
+        "rays": {"Grays_per_s": (st.extension_rays + st.shadow_rays) * world / elapsed / 1e9,
+                 "extension_rays_per_path": st.extension_rays / max(st.paths, 1),
+                 "shadow_rays_per_path": st.shadow_rays / max(st.paths, 1),
+                 "vertices_per_path": st.vertices / max(st.paths, 1),
+                 "algorithmic_bytes_per_path": st.algorithmic_bytes / max(st.paths, 1)},
+        "roofline": roofline,
+    }
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        out["cpu_baseline"] = cpu_baseline(host_scene, args, threads)
+        out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -224,6 +224,10 @@ int ptk_trace_primary(PtkScene* scene, const PtkRenderJob* job, int32_t* object_
 int ptk_trace_samples(PtkScene* scene, const PtkRenderJob* job, double* color, double* position, double* normal);
 
 int ptk_film_create(int32_t width, int32_t height, PtkFilm** out);
+/* A film over device buffers the caller owns (for instance tensors that a collective
+ * library reduces across GPUs); ptk_film_destroy() then leaves the buffers alone. */
+int ptk_film_wrap(int32_t width, int32_t height, double* d_image, double* d_position, double* d_normal,
+                  uint64_t* d_counters, PtkFilm** out);
 void ptk_film_destroy(PtkFilm* film);
 int ptk_film_clear(PtkFilm* film);
 /* Host <-> device copies of the three double[H*W*3] mean buffers and the per-pixel

@@ -189,10 +189,16 @@ def set_profiling(enabled):
 class Film:
     """Device-resident accumulation buffers: three float64 [H, W, 3] means + per-pixel counters."""
 
-    def __init__(self, width, height):
+    def __init__(self, width, height, device_buffers=None):
+        """`device_buffers`: optional (image, position, normal, counters) device addresses owned by the
+        caller (e.g. torch tensors' data_ptr()) to accumulate into instead of library-owned memory."""
         self.width, self.height = int(width), int(height)
         h = C.c_void_p()
-        _check_dev(device_lib().ptk_film_create(self.width, self.height, C.byref(h)))
+        if device_buffers is None:
+            _check_dev(device_lib().ptk_film_create(self.width, self.height, C.byref(h)))
+        else:
+            _check_dev(device_lib().ptk_film_wrap(self.width, self.height, *[C.c_void_p(int(p)) for p in device_buffers],
+                                                  C.byref(h)))
         self._handle = h
 
     def clear(self):

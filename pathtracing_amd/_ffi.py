@@ -80,6 +80,7 @@ PTK_OBJ_SPHERE, PTK_OBJ_PLANE, PTK_OBJ_RECTANGLE, PTK_OBJ_TRIANGLE, PTK_OBJ_MESH
 (PTK_MAT_DIFFUSE, PTK_MAT_REFLECTIVE, PTK_MAT_TRANSPARENT, PTK_MAT_GLOSSY, PTK_MAT_METALLIC_MICROFACET,
  PTK_MAT_REFLECTIVE_MICROFACET, PTK_MAT_TRANSPARENT_MICROFACET) = range(7)
 PTK_DENOISE_ATROUS, PTK_DENOISE_MEDIAN = 0, 1
+PTK_TRI_SMOOTH, PTK_TRI_HAS_UV = 1, 2
 
 dptr = C.POINTER(C.c_double)
 i32ptr = C.POINTER(C.c_int32)
@@ -113,6 +114,8 @@ DEVICE_PROTOTYPES = {
     "ptk_trace_primary": (C.c_int, [C.c_void_p, C.POINTER(PtkRenderJob), i32ptr, i32ptr, dptr, dptr, dptr]),
     "ptk_trace_samples": (C.c_int, [C.c_void_p, C.POINTER(PtkRenderJob), dptr, dptr, dptr]),
     "ptk_film_create": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "ptk_film_wrap": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.POINTER(C.c_void_p)]),
     "ptk_film_destroy": (None, [C.c_void_p]),
     "ptk_film_clear": (C.c_int, [C.c_void_p]),
     "ptk_film_upload": (C.c_int, [C.c_void_p, dptr, dptr, dptr, u64ptr]),

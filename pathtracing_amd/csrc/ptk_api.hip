@@ -151,6 +151,7 @@ constexpr int64_t DEFAULT_MAX_PATHS = int64_t(1) << 24;
 
 struct PtkFilm {
     int32_t width = 0, height = 0;
+    bool owns_buffers = true;
     double *image = nullptr, *position = nullptr, *normal = nullptr;
     unsigned long long* counters = nullptr;
 };
@@ -771,13 +772,32 @@ int ptk_film_create(int32_t width, int32_t height, PtkFilm** out) {
     return PTK_OK;
 }
 
+int ptk_film_wrap(int32_t width, int32_t height, double* d_image, double* d_position, double* d_normal, uint64_t* d_counters,
+                  PtkFilm** out) {
+    if (!out || width < 1 || height < 1 || !d_image || !d_position || !d_normal || !d_counters)
+        return fail(PTK_ERR_INVALID, "ptk_film_wrap: bad argument");
+    if (require_init() != PTK_OK) return PTK_ERR_DEVICE;
+    PtkFilm* f = new PtkFilm();
+    f->width = width;
+    f->height = height;
+    f->owns_buffers = false;
+    f->image = d_image;
+    f->position = d_position;
+    f->normal = d_normal;
+    f->counters = reinterpret_cast<unsigned long long*>(d_counters);
+    *out = f;
+    return PTK_OK;
+}
+
 void ptk_film_destroy(PtkFilm* f) {
     if (!f) return;
     if (g_stream) (void) hipStreamSynchronize(g_stream);
-    (void) hipFree(f->image);
-    (void) hipFree(f->position);
-    (void) hipFree(f->normal);
-    (void) hipFree(f->counters);
+    if (f->owns_buffers) {
+        (void) hipFree(f->image);
+        (void) hipFree(f->position);
+        (void) hipFree(f->normal);
+        (void) hipFree(f->counters);
+    }
     delete f;
 }
 

@@ -1,0 +1,88 @@
+"""The N > 1 path on CPU: two processes over gloo partition the samples (or the rows) of a frame,
+render their share with the CPU oracle standing in for the GPU, and combine their films with the
+same weighted-mean all-reduce bench.py uses over RCCL."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import pathtracing_amd as pt
+from pathtracing_amd import scenes
+from pathtracing_amd.distributed import combine_films, row_bands, sample_slice
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_sample_slices_cover_all_samples_exactly_once():
+    for world in (1, 2, 3, 8):
+        for total in (0, 1, 7, 8, 1024, 1027):
+            covered = []
+            for r in range(world):
+                first, count = sample_slice(r, world, total)
+                covered += list(range(first, first + count))
+            assert covered == list(range(total))
+            counts = [sample_slice(r, world, total)[1] for r in range(world)]
+            assert max(counts) - min(counts) <= 1
+
+
+def test_row_bands_cover_all_pixels_exactly_once():
+    for world in (1, 2, 4, 8):
+        for (w, h, band) in [(64, 48, 8), (37, 29, 8), (16, 5, 2)]:
+            seen = np.zeros(w * h, dtype=int)
+            for r in range(world):
+                for start, n in row_bands(r, world, w, h, band):
+                    seen[start:start + n] += 1
+            assert (seen == 1).all()
+
+
+def _worker(rank, world, port, scene_dir, mode, out_dir):
+    sys.path.insert(0, ROOT)
+    from oracle import binding as ob
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hs = pt.load_scene_directory(scene_dir)
+    W, H = hs.settings.width, hs.settings.height
+    osc = ob.OracleScene(hs)
+    img, pos, nrm = np.zeros((H, W, 3)), np.zeros((H, W, 3)), np.zeros((H, W, 3))
+    cnt = np.zeros((H, W), dtype=np.uint64)
+    total_spp = 5
+    if mode == "samples":
+        first, count = sample_slice(rank, world, total_spp)
+        if count:
+            osc.render(pt.make_job(0, W * H, count, first, 9), img, pos, nrm, cnt)
+    else:
+        for start, n in row_bands(rank, world, W, H, 8):
+            osc.render(pt.make_job(start, n, total_spp, 0, 9), img, pos, nrm, cnt)
+    t = [torch.from_numpy(a.reshape(-1)) for a in (img, pos, nrm)]
+    tc = torch.from_numpy(cnt.astype(np.int64).reshape(-1))
+    combine_films(t[0], t[1], t[2], tc)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, f"{mode}.npz"), image=t[0].numpy(), position=t[1].numpy(), normal=t[2].numpy(),
+                 counters=tc.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["samples", "rows"])
+def test_two_ranks_reproduce_the_single_process_image(tmp_path, mode):
+    from oracle import binding as ob
+    d = scenes.cornell_example(str(tmp_path / "ex"), WIDTH=32, HEIGHT=24)
+    port = 29500 + (os.getpid() % 2000) + (0 if mode == "samples" else 1)
+    mp.spawn(_worker, args=(2, port, d, mode, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(str(tmp_path / f"{mode}.npz"))
+    hs = pt.load_scene_directory(d)
+    W, H = hs.settings.width, hs.settings.height
+    img, pos, nrm = np.zeros((H, W, 3)), np.zeros((H, W, 3)), np.zeros((H, W, 3))
+    cnt = np.zeros((H, W), dtype=np.uint64)
+    ob.OracleScene(hs).render(pt.make_job(0, W * H, 5, 0, 9), img, pos, nrm, cnt)
+    assert np.array_equal(got["counters"], cnt.reshape(-1).astype(np.int64))
+    if mode == "rows":  # disjoint pixels: only the weighting round trip (x * n / n) can perturb the last bit
+        np.testing.assert_allclose(got["image"], img.reshape(-1), rtol=1e-15, atol=0)
+    else:               # sums of per-slice means: equal up to summation order
+        np.testing.assert_allclose(got["image"], img.reshape(-1), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(got["position"], pos.reshape(-1), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(got["normal"], nrm.reshape(-1), rtol=1e-12, atol=1e-15)

@@ -1,0 +1,220 @@
+"""Host front end: settings / scene / denoising JSON, OBJ subset, .map textures, mmap'd buffers.
+Behaviour follows the reference loaders (src/scene.cpp, src/objectunion.cpp:144-443,
+src/valuemap.cpp:54-91, src/utils.cpp:245-280)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import pathtracing_amd as pt
+from pathtracing_amd import _ffi, scenes
+
+
+def test_default_settings_are_the_reference_defaults():
+    s = pt.default_settings()
+    assert (s.width, s.height, s.samples_per_pixel, s.samples_per_iteration) == (1000, 1000, 10, 16)
+    assert (s.max_recursion_depth, s.min_recursion_steps, s.number_of_threads) == (100, 3, 1)
+    assert (s.use_gamma_correction, s.bvh_leaf_size, s.bvh_n_axis_splits) == (1, 4, 16)
+    assert (s.enable_next_event_estimation, s.enable_anti_aliasing) == (1, 1)
+
+
+def test_settings_keys_and_validation(tmp_path):
+    p = tmp_path / "settings.json"
+    p.write_text(json.dumps({"WIDTH": 320, "HEIGHT": 200, "samples_per_pixel": 7, "enable_anti_aliasing": False,
+                             "use_gamma_correction": False, "number_of_threads": 1}))
+    s = pt.load_settings(str(p))
+    assert (s.width, s.height, s.samples_per_pixel, s.enable_anti_aliasing, s.use_gamma_correction) == (320, 200, 7, 0, 0)
+    assert s.samples_per_iteration == 16  # absent keys keep their defaults
+    for bad, message in [({"samples_per_iteration": 0}, "samples_per_iteration"), ({"number_of_threads": 0}, "number_of_threads"),
+                         ({"bvh_leaf_size": 0}, "bvh_leaf_size"), ({"bvh_n_axis_splits": 0}, "bvh_n_axis_splits")]:
+        p.write_text(json.dumps(bad))
+        with pytest.raises(pt.PtkError, match=message):
+            pt.load_settings(str(p))
+    with pytest.raises(pt.PtkError, match="Could not open file"):
+        pt.load_settings(str(tmp_path / "missing.json"))
+
+
+def test_example_scene_tables(tmp_path):
+    d = scenes.cornell_example(str(tmp_path / "ex"), WIDTH=32, HEIGHT=16)
+    hs = pt.load_scene_directory(d)
+    desc = hs.desc
+    assert desc.n_objects == 12 and desc.n_materials == 9 and desc.n_media == 3 and desc.n_maps == 9
+    assert hs.object_names[0] == "floor" and hs.object_names[-1] == "light_source"
+    kinds = [desc.objects[i].type for i in range(12)]
+    assert kinds.count(_ffi.PTK_OBJ_RECTANGLE) == 7 and kinds.count(_ffi.PTK_OBJ_SPHERE) == 5
+    light = desc.materials[desc.objects[11].material]
+    assert light.is_light_source == 1 and light.type == _ffi.PTK_MAT_DIFFUSE
+    # colour maps are converted sRGB -> linear at load when use_gamma_correction is on; 1-channel maps never
+    red = desc.maps[0]
+    assert abs(desc.map_data[red.offset] - ((0.8 + 0.055) / 1.055) ** 2.4) < 1e-15
+    strength = [desc.maps[i] for i in range(9) if desc.maps[i].dim == 1][-1]
+    assert desc.map_data[strength.offset] == 40.0
+    assert desc.camera.orientation_x == 90 and desc.camera.dof_mode == 0
+    hs2 = pt.load_scene_directory(d, use_gamma_correction=0)
+    assert hs2.desc.map_data[hs2.desc.maps[0].offset] == 0.8
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/scenes/example"), reason="reference tree not present")
+def test_generated_example_equals_the_reference_scene_file(tmp_path):
+    ours = pt.load_scene_directory(scenes.cornell_example(str(tmp_path / "ex"), WIDTH=1000, HEIGHT=1000))
+    theirs = pt.load_scene_directory("/root/reference/scenes/example")
+    a, b = ours.desc, theirs.desc
+    assert ours.object_names == theirs.object_names
+    assert bytes(a.camera) == bytes(b.camera)
+    for i in range(a.n_objects):
+        assert bytes(a.objects[i]) == bytes(b.objects[i])
+    for i in range(a.n_materials):
+        assert bytes(a.materials[i]) == bytes(b.materials[i])
+    for i in range(a.n_media):
+        assert bytes(a.media[i]) == bytes(b.media[i])
+    assert [a.map_data[i] for i in range(a.n_map_values)] == [b.map_data[i] for i in range(b.n_map_values)]
+    for key in ("samples_per_pixel", "samples_per_iteration", "max_recursion_depth", "min_recursion_steps"):
+        assert getattr(ours.settings, key) == getattr(theirs.settings, key)
+
+
+def _scene_with(objects, materials=None, maps=None):
+    return {"valuemaps": maps or [], "media": [scenes._medium("air", "BeersLawMedium", [0, 0, 0], [0, 0, 0], 1.0)],
+            "materials": materials or [scenes._material("m", "Diffuse")], "objects": objects, "background_medium": "air",
+            "camera": scenes._camera([0, 0, 3], 90, 0, 0, 0.036, 0.036)}
+
+
+def test_scene_errors_use_the_reference_messages():
+    s = pt.default_settings()
+    base = _scene_with([])
+    for mutate, message in [
+        (lambda d: d.pop("media"), "JSON structure missing key 'media'"),
+        (lambda d: d.pop("background_medium"), "missing key 'background_medium'"),
+        (lambda d: d.update(background_medium="fog"), "Medium entry 'fog' does not exist"),
+        (lambda d: d["materials"].append(scenes._material("m", "Diffuse")), "Duplicate material entry 'm' found"),
+        (lambda d: d["materials"].append(scenes._material("x", "Velvet")), "Velvet is not a valid material type"),
+        (lambda d: d["objects"].append(scenes._sphere("s", [0, 0, 0], 1, "nope")), "Material entry 'nope' does not exist"),
+        (lambda d: d["objects"].append({"name": "o", "type": "Object", "subtype": "Cube", "parameters": {"material": "m"}}),
+         "Cube is not a valid object type"),
+        (lambda d: d["objects"].append({"name": "o", "type": "Object", "subtype": "Sphere",
+                                        "parameters": {"material": "m", "position": [0, 0], "radius": 1}}),
+         "should contain 3 elements, but contains 2"),
+        (lambda d: d["camera"].update(depth_of_field_mode="hexagon", focus_distance=1, aperture_size=0.1),
+         "Invalid 'depth_of_field_mode' hexagon"),
+    ]:
+        d = json.loads(json.dumps(base))
+        mutate(d)
+        with pytest.raises(pt.PtkError, match=message):
+            pt.HostScene.from_text(json.dumps(d), s)
+    with pytest.raises(pt.PtkError, match="JSON parse error"):
+        pt.HostScene.from_text("{ not json", s)
+
+
+def _load_obj(tmp_path, text, **params):
+    (tmp_path / "m.obj").write_text(text)
+    obj = {"name": "mesh", "type": "Object", "subtype": "ObjectUnion", "parameters": dict(file="m.obj", material="m", **params)}
+    hs = pt.HostScene.from_text(json.dumps(_scene_with([obj])), pt.default_settings(), str(tmp_path))
+    n = hs.desc.n_triangles
+    v = np.array([hs.desc.tri_vertices[i] for i in range(9 * n)]).reshape(n, 3, 3)
+    flags = [hs.desc.tri_flags[i] for i in range(n)]
+    return hs, v, flags
+
+
+def test_obj_subset_quads_spacing_and_index_forms(tmp_path):
+    text = ("# comment\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvn 0 0 1\n"
+            "f 1 2 3 4\n"            # quad -> (1,2,3) + (1,3,4)
+            "f 1/1 2/2 3/3\n"        # v/vt
+            "f 1//1 2//1 3//1\n"     # v//vn
+            "f 1/1/1 2/2/1 3/3/1\n"  # v/vt/vn
+            "f 1 2  3\n"             # double space: 4 spaces but an empty field -> dropped like the reference
+            "f 1 2 3 4 1\n")         # five corners: silently dropped
+    hs, v, flags = _load_obj(tmp_path, text, enable_smooth_shading=True)
+    assert len(v) == 5
+    assert np.array_equal(v[0], [[0, 0, 0], [1, 0, 0], [1, 1, 0]]) and np.array_equal(v[1], [[0, 0, 0], [1, 1, 0], [0, 1, 0]])
+    assert flags == [0, 0, _ffi.PTK_TRI_HAS_UV, _ffi.PTK_TRI_SMOOTH, _ffi.PTK_TRI_HAS_UV | _ffi.PTK_TRI_SMOOTH]
+    uv = [hs.desc.tri_uv[6 * 2 + i] for i in range(6)]
+    assert uv == [0, 0, 1, 0, 1, 1]
+    hs2, _, flags2 = _load_obj(tmp_path, text)  # smooth shading off: normals ignored
+    assert flags2 == [0, 0, _ffi.PTK_TRI_HAS_UV, 0, _ffi.PTK_TRI_HAS_UV]
+
+
+def test_obj_transform_applies_only_with_a_center(tmp_path):
+    text = "v -2 0 0\nv 2 0 0\nv 0 4 0\nf 1 2 3\n"
+    _, v, _ = _load_obj(tmp_path, text, size=3.0)  # no center: untouched
+    assert np.array_equal(v[0], [[-2, 0, 0], [2, 0, 0], [0, 4, 0]])
+    _, v, _ = _load_obj(tmp_path, text, center=[10, 0, 0], size=3.0)
+    mid = np.array([0, 2, 0.0])
+    far = max(np.linalg.norm(p - mid) for p in np.array([[-2, 0, 0], [2, 0, 0], [0, 4, 0.0]]))
+    want = (np.array([[-2, 0, 0], [2, 0, 0], [0, 4, 0.0]]) - mid) / far * 3.0 + np.array([10, 0, 0.0])
+    np.testing.assert_allclose(v[0], want, rtol=1e-15, atol=1e-15)
+    _, v, _ = _load_obj(tmp_path, text, center=[0, 0, 0], orientation={"X": 0, "Y": 90, "Z": 0})
+    np.testing.assert_allclose(v[0][1], [0, -2, -2], atol=1e-12)  # (2,-2,0) rotated 90 degrees about y
+
+
+def test_obj_errors(tmp_path):
+    with pytest.raises(pt.PtkError, match="Could not open file 'm2.obj'"):
+        obj = {"name": "mesh", "type": "Object", "subtype": "ObjectUnion", "parameters": {"file": "m2.obj", "material": "m"}}
+        pt.HostScene.from_text(json.dumps(_scene_with([obj])), pt.default_settings(), str(tmp_path))
+    with pytest.raises(pt.PtkError, match="out of range"):
+        _load_obj(tmp_path, "v 0 0 0\nv 1 0 0\nf 1 2 3\n")
+
+
+def test_map_files_round_trip_and_validation(tmp_path):
+    tex = np.arange(2 * 3 * 3, dtype=np.float64).reshape(2, 3, 3) / 18.0
+    pt.write_map(str(tmp_path / "a.map"), tex)
+    raw = np.fromfile(str(tmp_path / "a.map"))
+    assert list(raw[:3]) == [3, 2, 3] and np.array_equal(raw[3:], tex.ravel())
+    maps = [{"name": "a", "type": "ValueMap3D", "parameters": {"file": "a.map"}}]
+    scene = _scene_with([scenes._sphere("s", [0, 0, 0], 1, "m")], [scenes._material("m", "Diffuse", albedo_map="a")], maps)
+    s = pt.default_settings()
+    s.use_gamma_correction = 0
+    hs = pt.HostScene.from_text(json.dumps(scene), s, str(tmp_path))
+    m = hs.desc.maps[0]
+    assert (m.width, m.height, m.dim) == (3, 2, 3)
+    assert [hs.desc.map_data[m.offset + i] for i in range(18)] == list(tex.ravel())
+    s.use_gamma_correction = 1
+    hs = pt.HostScene.from_text(json.dumps(scene), s, str(tmp_path))
+    x = tex.ravel()[5]
+    assert abs(hs.desc.map_data[m.offset + 5] - ((x + 0.055) / 1.055) ** 2.4) < 1e-15
+    np.array([3.0, 2.0, 3.0, 1.0]).tofile(str(tmp_path / "bad.map"))
+    scene["valuemaps"][0]["parameters"]["file"] = "bad.map"
+    with pytest.raises(pt.PtkError, match="does not follow the expected format"):
+        pt.HostScene.from_text(json.dumps(scene), s, str(tmp_path))
+
+
+def test_denoising_pipeline_and_validation(tmp_path):
+    s = pt.default_settings()
+    s.width, s.height = 64, 48
+    p = tmp_path / "denoising.json"
+    p.write_text(json.dumps({"pipeline": [
+        {"mode": "median", "parameters": {"kernel_size": 3, "threshold": 0.5}},
+        {"mode": "skip", "parameters": {}},
+        {"mode": "atrous", "parameters": {"iterations": 4, "sigma_rt": 2, "sigma_x": 2, "sigma_n": 1}}]}))
+    tasks = pt.load_denoising(str(p), s)
+    assert len(tasks) == 2 and tasks[0].mode == _ffi.PTK_DENOISE_MEDIAN and tasks[0].kernel_size == 3
+    assert tasks[1].iterations == 4 and tasks[1].sigma_n == 1.0
+    for pipeline, message in [([{"mode": "atrous", "parameters": {"iterations": 6, "sigma_rt": 1, "sigma_x": 1, "sigma_n": 1}}],
+                               "Too many denoising iterations"),
+                              ([{"mode": "median", "parameters": {"kernel_size": 49, "threshold": 0}}], "kernel size is too large"),
+                              ([{"mode": "median", "parameters": {"kernel_size": 3, "threshold": -1}}], "cannot be negative"),
+                              ([{"mode": "blur", "parameters": {}}], "'blur' is not a valid denoising mode"),
+                              ([{"mode": "median", "parameters": {"kernel_size": 3}}], "missing key 'threshold'")]:
+        p.write_text(json.dumps({"pipeline": pipeline}))
+        with pytest.raises(pt.PtkError, match=message):
+            pt.load_denoising(str(p), s)
+
+
+def test_accumulation_buffer_files(tmp_path):
+    """temp/raw_*.dat: float64 [H][W][3], shared mapping, truncated on request (src/utils.cpp:245-273)."""
+    import ctypes as C
+    lib = pt.host_lib()
+    path = str(tmp_path / "raw_pixel.dat").encode()
+    size = 4 * 3 * 3 * 8
+    fd = C.c_int()
+    ptr = lib.ptk_host_map_buffer(path, size, 1, C.byref(fd))
+    assert ptr
+    a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(3, 4, 3))
+    assert not a.any()
+    a[1, 2] = [1.5, 2.5, 3.5]
+    lib.ptk_host_unmap_buffer(ptr, size, fd)
+    b = np.fromfile(path.decode()).reshape(3, 4, 3)
+    assert list(b[1, 2]) == [1.5, 2.5, 3.5] and os.stat(path.decode()).st_mode & 0o777 == 0o600
+    ptr = lib.ptk_host_map_buffer(path, size, 0, C.byref(fd))  # re-open without clearing, as the denoiser does
+    a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(3, 4, 3))
+    assert list(a[1, 2]) == [1.5, 2.5, 3.5]
+    lib.ptk_host_unmap_buffer(ptr, size, fd)

@@ -1,0 +1,114 @@
+"""The CPU oracle against fixtures produced by the reference itself (tests/golden/make_golden.py).
+
+With the reference's three generators re-seeded and the oracle consuming the same sequential
+streams, every sample's radiance / first-hit position / normal must be bit-identical; so must the
+primary-hit buffers (no random numbers involved), the denoiser outputs and the pure helpers."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import make_golden  # noqa: E402  (scene table shared with the generator; importing runs nothing)
+
+import pathtracing_amd as pt  # noqa: E402
+from oracle import binding as ob  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def built(tmp_path_factory):
+    root = tmp_path_factory.mktemp("golden_scenes")
+    dirs = {}
+    for name in make_golden.SCENES:
+        d = str(root / name)
+        make_golden.build_scene(name, d)
+        dirs[name] = d
+    return dirs
+
+
+@pytest.mark.parametrize("name", [n for n in make_golden.SCENES if "circle" not in n and "square" not in n])
+def test_primary_hits_bit_exact(built, name):
+    g = np.load(os.path.join(GOLDEN, f"primary_{name}.npz"))
+    hs = pt.load_scene_directory(built[name], enable_anti_aliasing=0)
+    n = hs.settings.width * hs.settings.height
+    obj, face, dist, pos, nrm = ob.OracleScene(hs).trace_primary(pt.make_job(0, n, 1, 0, 0))
+    assert np.array_equal(obj, g["object"])
+    assert np.array_equal(face, g["face"])
+    assert np.array_equal(dist, g["distance"])
+    assert np.array_equal(pos, g["position"])
+    assert np.array_equal(nrm, g["normal"])
+
+
+@pytest.mark.parametrize("name", list(make_golden.SCENES))
+def test_samples_bit_exact_with_reference_streams(built, name):
+    g = np.load(os.path.join(GOLDEN, f"samples_{name}.npz"))
+    hs = pt.load_scene_directory(built[name])
+    n = hs.settings.width * hs.settings.height
+    rng = ob.stream_rng(*[int(s) for s in g["seeds"]])
+    color, pos, nrm = ob.OracleScene(hs).trace_samples(pt.make_job(0, n, int(g["spp"]), 0, 0), rng)
+    assert np.array_equal(color, g["color"], equal_nan=True)
+    assert np.array_equal(pos, g["position"], equal_nan=True)
+    assert np.array_equal(nrm, g["normal"], equal_nan=True)
+
+
+def test_denoise_bit_exact():
+    g = np.load(os.path.join(GOLDEN, "denoise.npz"))
+    pipelines = {
+        "shipped": [{"mode": "median", "kernel_size": 3, "threshold": 0.5},
+                    {"mode": "atrous", "iterations": 4, "sigma_rt": 2, "sigma_x": 2, "sigma_n": 2}],
+        "atrous2": [{"mode": "atrous", "iterations": 2, "sigma_rt": 0.7, "sigma_x": 1.5, "sigma_n": 0.4}],
+        "median5": [{"mode": "median", "kernel_size": 5, "threshold": 0.05}],
+        "median7": [{"mode": "median", "kernel_size": 7, "threshold": 0.0}],
+        "zero_sigma": [{"mode": "atrous", "iterations": 1, "sigma_rt": 1, "sigma_x": 0, "sigma_n": 1}],
+    }
+    for key, pipeline in pipelines.items():
+        out = ob.oracle_denoise(pt.make_denoise_tasks(pipeline), g["image"], g["position"], g["normal"])
+        assert np.array_equal(out, g["out_" + key], equal_nan=True), key
+
+
+def test_helper_functions_bit_exact():
+    g = np.load(os.path.join(GOLDEN, "helpers.npz"))
+    o = ob.oracle_lib()
+    d3 = ob.d3
+    for i in range(len(g["cos"])):
+        c, n1, n2, k = float(g["cos"][i]), float(g["n1"][i]), float(g["n2"][i]), float(g["k"][i])
+        assert o.oracle_fresnel_dielectric(c, n1, n2) == g["fresnel_dielectric"][i]
+        assert o.oracle_fresnel_conductor(c, n1, 0.0, n2, k) == g["fresnel_conductor_out"][i]
+        got = o.oracle_fresnel_conductor(c, n1, k, n2, 0.0)
+        assert got == g["fresnel_conductor_in"][i] or (np.isnan(got) and np.isnan(g["fresnel_conductor_in"][i]))
+        assert o.oracle_schlick_fresnel(c, n1, n2) == g["schlick"][i]
+        v, a = g["vectors"][i], float(g["alpha"][i])
+        got = o.oracle_beckmann_D(d3(*v[0]), d3(*v[1]), a)
+        assert got == g["beckmann_D"][i] or (np.isnan(got) and np.isnan(g["beckmann_D"][i]))
+        got = o.oracle_smith_G1(d3(*v[0]), d3(*v[1]), d3(*v[2]), a)
+        assert got == g["smith_G1"][i] or (np.isnan(got) and np.isnan(g["smith_G1"][i]))
+        out = d3()
+        o.oracle_rotate(d3(*v[0]), *[float(x) for x in g["angles"][i]], out)
+        assert list(out) == list(g["rotate"][i])
+        o.oracle_refract(d3(*v[0]), d3(*v[1]), n1 / n2, out)
+        assert list(out) == list(g["refract"][i])
+        dist = C.c_double()
+        ok = o.oracle_solve_quadratic(float(g["quad_b"][i]), float(g["quad_c"][i]), C.byref(dist))
+        assert (not ok and np.isnan(g["quad_root"][i])) or (ok and dist.value == g["quad_root"][i])
+
+
+def test_counter_streams_converge_to_the_reference_image(built):
+    """The same estimator with the ABI's counter-based generator against the reference's own
+    high-sample image.  The scene has caustic paths with heavy-tailed sample values, so the comparison
+    uses the mean absolute error (two independent 1024-sample renders of this scene differ by about
+    0.07 relative MAE per channel) and the channel means."""
+    g = np.load(os.path.join(GOLDEN, "converged_example.npz"))
+    hs = pt.load_scene_directory(built["example"])
+    W, H = hs.settings.width, hs.settings.height
+    image, pos, nrm = np.zeros((H, W, 3)), np.zeros((H, W, 3)), np.zeros((H, W, 3))
+    cnt = np.zeros((H, W), dtype=np.uint64)
+    ob.OracleScene(hs).render(pt.make_job(0, W * H, 512, 0, 5), image, pos, nrm, cnt, threads=8)
+    ref = g["image"].astype(np.float64)
+    for c in range(3):
+        mae = np.mean(np.abs(image[..., c] - ref[..., c])) / np.mean(ref[..., c])
+        assert mae < 0.2, (c, mae)
+        assert abs(image[..., c].mean() - ref[..., c].mean()) / ref[..., c].mean() < 0.06
