@@ -14,4 +14,9 @@ hipcc $HIPFLAGS -c ptk_api.hip -o build/ptk_api.o &
 g++ -std=c++17 -O3 -fPIC -I../../include -I. -c host/bvh_builder.cpp -o build/bvh_builder.o &
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC build/kernels.o build/denoise.o build/ptk_api.o build/bvh_builder.o -o $OUT/libptk.so -lpthread
-echo "built $OUT/libptkhost.so $OUT/libptk.so"
+mkdir -p $OUT/bin
+for app in pathtracer denoiser; do
+  g++ -std=c++17 -O2 -Wall -Wextra -I../../include app/${app}_main.cpp -o $OUT/bin/$app -L$OUT -lptk -lptkhost \
+      -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath-link,/opt/rocm/lib
+done
+echo "built $OUT/libptkhost.so $OUT/libptk.so $OUT/bin/pathtracer $OUT/bin/denoiser"
