@@ -8,6 +8,7 @@
 namespace ptk {
 
 #define PTK_DEV __device__ __forceinline__
+#define PTK_CONSTANT __attribute__((address_space(4)))
 
 constexpr double PI = 3.14159265358979323846;
 constexpr double INF = __builtin_huge_val();

@@ -96,18 +96,18 @@ struct TraversalStack {
 // Closest triangle of one mesh.  Children are visited nearest first and skipped when their entry
 // distance is not below the best hit so far (Node::intersect, src/bvh.cpp:193-213); the slab test is
 // BoundingBox::intersect (:60-83) evaluated on the outward-rounded fp32 boxes.
-PTK_DEV void mesh_closest_hit(const DevScene& sc, const DevObject& o, const V3& org, const V3& dir, const RayPrep& rp,
-                              double& t_best, int& prim_best, TraversalStack& st) {
-    if (o.bvh_root < 0) return;
+PTK_DEV void mesh_closest_hit(const DevScene& sc, int32_t bvh_root, int64_t first_tri, const V3& org, const V3& dir,
+                              const RayPrep& rp, double& t_best, int& prim_best, TraversalStack& st) {
+    if (bvh_root < 0) return;
     const double idx = 1.0 / dir.x, idy = 1.0 / dir.y, idz = 1.0 / dir.z;
     st.sp = 0;
-    st.push(o.bvh_root, 0.0f);
+    st.push(bvh_root, 0.0f);
     while (st.sp > 0) {
         StackEntry e = st.pop();
         if (static_cast<double>(e.tnear) >= t_best) continue;
         if (e.node < 0) { // leaf
             uint32_t code = static_cast<uint32_t>(~e.node);
-            int64_t first = o.first_tri + (code >> 3);
+            int64_t first = first_tri + (code >> 3);
             int count = static_cast<int>(code & 7u) + 1;
             for (int i = 0; i < count; i++) {
                 double d;
@@ -171,8 +171,11 @@ PTK_DEV bool closest_hit(const DevScene& sc, const V3& org, const V3& dir, doubl
     if (sc.has_triangles) rp = prepare_ray(dir);
     const double dir_dot_org = dot(dir, org);
     double limit = t_max; // ray.t_max
+    // The object table is read through the constant address space: the index is wave-uniform, so the
+    // fields arrive by scalar loads and live in SGPRs instead of costing a vector load per lane.
+    const PTK_CONSTANT DevObject* objects = (const PTK_CONSTANT DevObject*) sc.objects;
     for (int i = 0; i < sc.n_objects; i++) {
-        const DevObject& o = sc.objects[i];
+        const PTK_CONSTANT DevObject& o = objects[i];
         double d = INF;
         int prim = 0;
         bool success = false;
@@ -204,7 +207,7 @@ PTK_DEV bool closest_hit(const DevScene& sc, const V3& org, const V3& dir, doubl
         else { // mesh
             double tb = limit;
             int pb = -1;
-            mesh_closest_hit(sc, o, org, dir, rp, tb, pb, st);
+            mesh_closest_hit(sc, o.bvh_root, o.first_tri, org, dir, rp, tb, pb, st);
             if (pb >= 0) {
                 success = true;
                 d = tb;

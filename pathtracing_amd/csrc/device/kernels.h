@@ -6,20 +6,24 @@
 
 namespace ptk {
 
-void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathPool& pool, const SampleResults& res);
-void launch_extend(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathPool& pool, uint32_t n_active,
-                   const HitRecords& hits, uint32_t* queues, uint32_t queue_stride, BounceCounters* counters,
-                   const SampleResults& res);
-// `bound` is an upper bound of the class's queue length, used only to size the grid; the kernel
-// reads the true length from `counters`.
-void launch_shade(hipStream_t s, int cls, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in,
-                  const PathPool& out, const HitRecords& hits, const uint32_t* queue, BounceCounters* counters,
-                  const ShadowQueue& shadow, const SampleResults& res);
-void launch_connect(hipStream_t s, uint32_t bound, const DevScene& sc, const ShadowQueue& shadow, const BounceCounters* counters,
-                    const SampleResults& res, unsigned long long* ray_counter);
-void launch_accumulate(hipStream_t s, const BatchParams& b, const SampleResults& res, double* image, double* position,
-                       double* normal, unsigned long long* pixel_counters);
-void launch_gather_samples(hipStream_t s, const BatchParams& b, const SampleResults& res, size_t pixel_base, double* color,
+// number of blocks k_extend / k_bin_scatter use for a list of n entries (= rows of block_counts used)
+uint32_t bin_blocks(uint32_t n);
+
+void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathState& ps, uint32_t* list);
+void launch_extend(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathState& ps, const uint32_t* list, uint32_t n,
+                   uint32_t* block_counts, uint32_t count_stride, unsigned long long* ray_counter);
+// scan + scatter: list_in (n entries) -> class-sorted list_out, summary in *info
+void launch_bin(hipStream_t s, const DevScene& sc, const PathState& ps, const uint32_t* list_in, uint32_t n, uint32_t* block_counts,
+                uint32_t count_stride, BinInfo* info, uint32_t* list_out);
+// `bound` is an upper bound of the number of entries, used only to size the grid; the kernels read
+// the true counts from *info.
+void launch_shade(hipStream_t s, int cls, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathState& ps,
+                  const uint32_t* list, const BinInfo* info);
+void launch_connect(hipStream_t s, uint32_t bound, const DevScene& sc, const PathState& ps, const uint32_t* list, const BinInfo* info,
+                    unsigned long long* ray_counter);
+void launch_accumulate(hipStream_t s, const BatchParams& b, const PathState& ps, double* image, double* position, double* normal,
+                       unsigned long long* pixel_counters);
+void launch_gather_samples(hipStream_t s, const BatchParams& b, const PathState& ps, size_t pixel_base, double* color,
                            double* position, double* normal);
 void launch_primary(hipStream_t s, const DevScene& sc, const BatchParams& b, int32_t* object_index, int32_t* primitive_index,
                     double* distance, double* position, double* normal);

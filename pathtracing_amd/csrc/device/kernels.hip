@@ -1,18 +1,23 @@
 // Wavefront path-tracing kernels for gfx950.
 //
-//   k_generate   camera samples -> path state            (compute_pixel_color + Camera::make_ray)
-//   k_extend     free-flight distance + closest hit, then sorts the path into the queue of the
-//                material class it hit                    (raytrace's loop head + find_closest_hit)
-//   k_shade<C>   one launch per material class: emission with MIS, next-event sampling up to the
-//                shadow-ray record, BRDF sampling, medium switch, Russian roulette; survivors are
-//                written densely into the other pool       (raytrace's loop body)
-//   k_connect    visibility march of the queued shadow rays (compute_visibility)
-//   k_accumulate per-pixel sample means folded into the film (compute_pixel_color's division and
-//                increment_average)
+//   k_generate     camera samples -> path state              (compute_pixel_color + Camera::make_ray)
+//   k_extend       free-flight distance + closest hit; records the material class the path hit and
+//                  leaves per-block class counts               (raytrace's loop head + find_closest_hit)
+//   k_bin_scan     exclusive scan of the per-block class counts
+//   k_bin_scatter  writes the class-sorted list of live paths  (stable: list order is preserved)
+//   k_shade<C>     one launch per material class over its segment of the list: emission with MIS,
+//                  next-event sampling up to the shadow-ray record, BRDF sampling, medium switch,
+//                  Russian roulette; state is updated in place  (raytrace's loop body)
+//   k_connect      visibility march of the pending shadow rays  (compute_visibility)
+//   k_accumulate   per-pixel sample means folded into the film  (compute_pixel_color's division and
+//                  increment_average)
 //
-// One lane owns one path.  Queues and the next pool are filled with one atomic per wave:
-// ballot -> mbcnt prefix -> lane 0 reserves the range.  All arithmetic is fp64, as in the
-// reference; MFMA has no role here (divergent scalar-per-lane work, no dense contraction).
+// One lane owns one path; a path keeps its slot for life and kernels reach the live paths through an
+// index list.  Sorting by class uses block-local ballots and a scan instead of global atomics: with
+// one atomic per wave on a shared counter the kernels ran at the rate of that one cache line
+// (about 100 atomics per microsecond) instead of at the rate of the arithmetic.  All arithmetic is
+// fp64, as in the reference; MFMA has no role here (divergent scalar-per-lane work, no dense
+// contraction).
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -21,22 +26,7 @@
 namespace ptk {
 
 constexpr int BLOCK = 256;
-
-// ---- wave-level append ------------------------------------------------------------------------
-// Reserves one slot for every lane with `active` set; returns the lane's slot (undefined when not
-// active).  One atomic per wave.
-PTK_DEV uint32_t wave_append(uint32_t* counter, bool active) {
-    const unsigned long long mask = __ballot(active);
-    const uint32_t total = static_cast<uint32_t>(__popcll(mask));
-    if (total == 0) return 0;
-    const uint32_t lane_prefix = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
-                                                           __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0));
-    uint32_t base = 0;
-    const int leader = __ffsll(static_cast<long long>(mask)) - 1;
-    if (static_cast<int>(__lane_id()) == leader) base = atomicAdd(counter, total);
-    base = __shfl(base, leader);
-    return base + lane_prefix;
-}
+static_assert(BLOCK == BIN_BLOCK, "k_extend and the bin kernels share their block geometry");
 
 PTK_DEV TraversalStack make_stack(StackEntry* lds) {
     TraversalStack st;
@@ -50,6 +40,10 @@ PTK_DEV void sample_coordinates(const BatchParams& b, uint32_t sid, uint32_t& pi
     uint32_t s = sid / b.n_pixels;
     pixel = static_cast<uint32_t>(b.start_idx) + (sid - s * b.n_pixels);
     sample = b.sample_offset + s;
+}
+
+PTK_DEV uint32_t lanes_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0));
 }
 
 // Camera sample of one path: AA jitter (app/pathtracer.cpp:185-188), Camera::make_ray and
@@ -91,344 +85,439 @@ PTK_DEV void camera_ray(const DevScene& sc, uint32_t pixel, Rng& rng, V3& org, V
 }
 
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, PathPool pool, SampleResults res) {
+__global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, PathState st, uint32_t* list) {
     for (uint32_t sid = blockIdx.x * BLOCK + threadIdx.x; sid < b.n_paths; sid += gridDim.x * BLOCK) {
         uint32_t pixel, sample;
         sample_coordinates(b, sid, pixel, sample);
         Rng rng{rng_key(b.seed, pixel, sample), 0};
         V3 org, dir;
         camera_ray(sc, pixel, rng, org, dir);
-        pool.ox[sid] = org.x;
-        pool.oy[sid] = org.y;
-        pool.oz[sid] = org.z;
-        pool.dx[sid] = dir.x;
-        pool.dy[sid] = dir.y;
-        pool.dz[sid] = dir.z;
-        pool.tx[sid] = 1.0;
-        pool.ty[sid] = 1.0;
-        pool.tz[sid] = 1.0;
-        pool.sx[sid] = 0.0;
-        pool.sy[sid] = 0.0;
-        pool.sz[sid] = 0.0;
-        pool.spdf[sid] = 0.0;
-        pool.sid[sid] = sid;
-        pool.ctr[sid] = rng.ctr;
-        pool.flags[sid] = 0u | (RAY_TRANSMITTED << TYPE_SHIFT) | (static_cast<uint32_t>(sc.background_medium) << 16);
-        res.cr[sid] = 0.0;
-        res.cg[sid] = 0.0;
-        res.cb[sid] = 0.0;
-        res.px[sid] = 0.0;
-        res.py[sid] = 0.0;
-        res.pz[sid] = 0.0;
-        res.nx[sid] = 0.0;
-        res.ny[sid] = 0.0;
-        res.nz[sid] = 0.0;
+        st.ox[sid] = org.x;
+        st.oy[sid] = org.y;
+        st.oz[sid] = org.z;
+        st.dx[sid] = dir.x;
+        st.dy[sid] = dir.y;
+        st.dz[sid] = dir.z;
+        st.tx[sid] = 1.0;
+        st.ty[sid] = 1.0;
+        st.tz[sid] = 1.0;
+        st.sx[sid] = 0.0;
+        st.sy[sid] = 0.0;
+        st.sz[sid] = 0.0;
+        st.spdf[sid] = 0.0;
+        st.ctr[sid] = rng.ctr;
+        st.flags[sid] = 0u | (RAY_TRANSMITTED << TYPE_SHIFT) | (static_cast<uint32_t>(sc.background_medium) << 16);
+        st.cls[sid] = 0;
+        st.sh_info[sid] = 0;
+        st.cr[sid] = 0.0;
+        st.cg[sid] = 0.0;
+        st.cb[sid] = 0.0;
+        st.px[sid] = 0.0;
+        st.py[sid] = 0.0;
+        st.pz[sid] = 0.0;
+        st.nx[sid] = 0.0;
+        st.ny[sid] = 0.0;
+        st.nz[sid] = 0.0;
+        list[sid] = sid;
     }
 }
 
 // -------------------------------------------------------------------------------------------------
 // Loop head of raytrace (app/pathtracer.cpp:53-67): free-flight distance, closest hit, miss handling.
-__global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, BatchParams b, PathPool pool, uint32_t n_active, HitRecords hits,
-                                                  uint32_t* queues, uint32_t queue_stride, BounceCounters* counters,
-                                                  SampleResults res) {
+// Block b owns list entries [b * BIN_CHUNK, (b + 1) * BIN_CHUNK) and leaves its per-class counts in
+// block_counts[class * count_stride + b].
+__global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, BatchParams b, PathState ps, const uint32_t* list, uint32_t n,
+                                                  uint32_t* block_counts, uint32_t count_stride, unsigned long long* ray_counter) {
     __shared__ StackEntry lds_stack[LDS_STACK_DEPTH * BLOCK];
+    __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
+    __shared__ uint32_t wave_rays[BLOCK / 64];
+    uint32_t my_rays = 0;
     TraversalStack st = make_stack(lds_stack);
-    const uint32_t rounds = (n_active + gridDim.x * BLOCK - 1) / (gridDim.x * BLOCK);
-    for (uint32_t r = 0; r < rounds; r++) { // every lane runs every round: the appends are wave-wide
-        const uint32_t slot = (r * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x;
-        const bool valid = slot < n_active;
+    uint32_t my_counts[N_CLASSES];
+    uint32_t wave_rays_acc = 0;
+#pragma unroll
+    for (int c = 0; c < N_CLASSES; c++) my_counts[c] = 0;
+    for (int r = 0; r < BIN_ROUNDS; r++) {
+        const uint32_t idx = blockIdx.x * BIN_CHUNK + r * BLOCK + threadIdx.x;
         int cls = -1;
-        if (valid) {
-            V3 org = v3(pool.ox[slot], pool.oy[slot], pool.oz[slot]);
-            V3 dir = v3(pool.dx[slot], pool.dy[slot], pool.dz[slot]);
-            const uint32_t flags = pool.flags[slot];
-            uint32_t medium = flags >> 16;
-            if (medium == MEDIUM_NONE) medium = static_cast<uint32_t>(sc.background_medium);
-            const DevMedium& med = sc.media[medium];
-            double scatter_distance = INF;
-            if (med.type == PTK_MEDIUM_HOMOGENEOUS_SCATTERING) { // HomogenousScatteringMedium::sample_distance
-                uint32_t pixel, sample;
-                const uint32_t sid = pool.sid[slot];
-                sample_coordinates(b, sid, pixel, sample);
-                Rng rng{rng_key(b.seed, pixel, sample), pool.ctr[slot]};
-                int channel = rng.integer(0, 3);
-                double ext = med.extinction[channel];
-                if (ext != 0) scatter_distance = -log(rng.u01()) / ext;
-            }
-            HitInfo h;
-            bool found = closest_hit(sc, org, dir, scatter_distance, h, st);
-            if (!found && scatter_distance == INF) {
-                // color += throughput * background_color; path ends
-                if (!sc.background_is_black) {
-                    const uint32_t sid = pool.sid[slot];
-                    res.cr[sid] += pool.tx[slot] * sc.background[0];
-                    res.cg[sid] += pool.ty[slot] * sc.background[1];
-                    res.cb[sid] += pool.tz[slot] * sc.background[2];
+        if (idx < n) {
+            const uint32_t slot = list[idx];
+            if (ps.cls[slot] != CLASS_DEAD) {
+                V3 org = v3(ps.ox[slot], ps.oy[slot], ps.oz[slot]);
+                V3 dir = v3(ps.dx[slot], ps.dy[slot], ps.dz[slot]);
+                const uint32_t flags = ps.flags[slot];
+                uint32_t medium = flags >> 16;
+                if (medium == MEDIUM_NONE) medium = static_cast<uint32_t>(sc.background_medium);
+                const DevMedium& med = sc.media[medium];
+                double scatter_distance = INF;
+                if (med.type == PTK_MEDIUM_HOMOGENEOUS_SCATTERING) { // HomogenousScatteringMedium::sample_distance
+                    uint32_t pixel, sample;
+                    sample_coordinates(b, slot, pixel, sample);
+                    Rng rng{rng_key(b.seed, pixel, sample), ps.ctr[slot]};
+                    int channel = rng.integer(0, 3);
+                    double ext = med.extinction[channel];
+                    if (ext != 0) scatter_distance = -log(rng.u01()) / ext;
+                }
+                HitInfo h;
+                bool found = closest_hit(sc, org, dir, scatter_distance, h, st);
+                my_rays = 1;
+                if (!found && scatter_distance == INF) {
+                    // color += throughput * background_color; the path ends
+                    if (!sc.background_is_black) {
+                        ps.cr[slot] += ps.tx[slot] * sc.background[0];
+                        ps.cg[slot] += ps.ty[slot] * sc.background[1];
+                        ps.cb[slot] += ps.tz[slot] * sc.background[2];
+                    }
+                    ps.cls[slot] = CLASS_DEAD;
+                }
+                else if (!found) { // scatter event before any surface
+                    ps.hit_t[slot] = scatter_distance;
+                    ps.hit_obj[slot] = -1;
+                    ps.hit_prim[slot] = 0;
+                    cls = CLASS_SCATTER;
+                    ps.cls[slot] = CLASS_SCATTER;
+                }
+                else {
+                    ps.hit_t[slot] = h.t;
+                    ps.hit_obj[slot] = h.obj;
+                    ps.hit_prim[slot] = h.prim;
+                    cls = sc.materials[sc.objects[h.obj].material].type;
+                    ps.cls[slot] = static_cast<uint8_t>(cls);
                 }
             }
-            else if (!found) { // scatter event before any surface
-                hits.t[slot] = scatter_distance;
-                hits.obj[slot] = -1;
-                hits.prim[slot] = 0;
-                cls = CLASS_SCATTER;
-            }
-            else {
-                hits.t[slot] = h.t;
-                hits.obj[slot] = h.obj;
-                hits.prim[slot] = h.prim;
-                cls = sc.materials[sc.objects[h.obj].material].type;
-            }
         }
-        // sort into per-class queues; classes absent from the scene are skipped
+#pragma unroll
+        for (int c = 0; c < N_CLASSES; c++)
+            if ((sc.class_mask >> c) & 1u) my_counts[c] += static_cast<uint32_t>(__popcll(__ballot(cls == c)));
+        wave_rays_acc += static_cast<uint32_t>(__popcll(__ballot(my_rays != 0)));
+        my_rays = 0;
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < N_CLASSES; c++) wave_counts[wave][c] = my_counts[c];
+        wave_rays[wave] = wave_rays_acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < N_CLASSES) {
+        uint32_t total = 0;
+        for (int w = 0; w < BLOCK / 64; w++) total += wave_counts[w][threadIdx.x];
+        block_counts[threadIdx.x * count_stride + blockIdx.x] = total;
+    }
+    if (threadIdx.x == 0) { // rays traced, for the statistics: one atomic per block
+        uint32_t total = 0;
+        for (int w = 0; w < BLOCK / 64; w++) total += wave_rays[w];
+        if (total) atomicAdd(ray_counter, static_cast<unsigned long long>(total));
+    }
+}
+
+// Exclusive scan, in class-major order, of block_counts[class * count_stride + block] for the first
+// n_blocks blocks of every class; one workgroup.  Leaves the offsets in place and the per-class
+// segment starts, counts and the total in `info`.
+__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* block_counts, uint32_t count_stride, uint32_t n_blocks, BinInfo* info) {
+    __shared__ uint32_t partial[1024];
+    __shared__ uint32_t class_start[N_CLASSES + 1];
+    const uint32_t elements = N_CLASSES * n_blocks;
+    const uint32_t per_thread = (elements + 1023) / 1024;
+    const uint32_t first = threadIdx.x * per_thread;
+    const uint32_t last = min(first + per_thread, elements);
+    uint32_t sum = 0;
+    for (uint32_t e = first; e < last; e++) {
+        uint32_t c = e / n_blocks, blk = e - c * n_blocks;
+        sum += block_counts[c * count_stride + blk];
+    }
+    partial[threadIdx.x] = sum;
+    __syncthreads();
+    // Hillis-Steele inclusive scan of the 1024 partial sums
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t v = threadIdx.x >= off ? partial[threadIdx.x - off] : 0;
+        __syncthreads();
+        partial[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t running = partial[threadIdx.x] - sum; // exclusive prefix of this thread's run
+    for (uint32_t e = first; e < last; e++) {
+        uint32_t c = e / n_blocks, blk = e - c * n_blocks;
+        uint32_t v = block_counts[c * count_stride + blk];
+        block_counts[c * count_stride + blk] = running;
+        if (blk == 0) class_start[c] = running;
+        running += v;
+    }
+    if (threadIdx.x == 1023) class_start[N_CLASSES] = partial[1023];
+    __syncthreads();
+    if (threadIdx.x < N_CLASSES) {
+        info->start[threadIdx.x] = class_start[threadIdx.x];
+        info->count[threadIdx.x] = class_start[threadIdx.x + 1] - class_start[threadIdx.x];
+    }
+    if (threadIdx.x == 0) info->total = class_start[N_CLASSES];
+}
+
+// Writes the class-sorted list: entry i of the input list with class c goes to
+// block_offsets[c][block] + (number of class-c entries before it in the block).  Paths that ended
+// (CLASS_DEAD) are dropped.
+__global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathState ps, const uint32_t* list_in, uint32_t n, const uint32_t* block_offsets,
+                                                       uint32_t count_stride, uint32_t class_mask, uint32_t* list_out) {
+    __shared__ uint32_t counts[BIN_ROUNDS][BLOCK / 64][N_CLASSES];
+    const int wave = threadIdx.x >> 6;
+    uint32_t slots[BIN_ROUNDS];
+    int classes[BIN_ROUNDS];
+    uint32_t below[BIN_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < BIN_ROUNDS; r++) {
+        const uint32_t idx = blockIdx.x * BIN_CHUNK + r * BLOCK + threadIdx.x;
+        int cls = -1;
+        uint32_t slot = 0;
+        if (idx < n) {
+            slot = list_in[idx];
+            const uint8_t c = ps.cls[slot];
+            if (c != CLASS_DEAD) cls = c;
+        }
+        slots[r] = slot;
+        classes[r] = cls;
+        below[r] = 0;
 #pragma unroll
         for (int c = 0; c < N_CLASSES; c++) {
-            if (!((sc.class_mask >> c) & 1u)) continue;
-            const bool mine = cls == c;
-            const uint32_t pos = wave_append(&counters->queue_count[c], mine);
-            if (mine) queues[static_cast<size_t>(c) * queue_stride + pos] = slot;
+            if (!((class_mask >> c) & 1u)) continue;
+            const unsigned long long m = __ballot(cls == c);
+            if (cls == c) below[r] = lanes_below(m);
+            if ((threadIdx.x & 63) == 0) counts[r][wave][c] = static_cast<uint32_t>(__popcll(m));
         }
     }
+    __syncthreads();
+    // exclusive prefix over (round, wave) for each class, plus the block's global offset
+    if (threadIdx.x < N_CLASSES && ((class_mask >> threadIdx.x) & 1u)) {
+        uint32_t running = block_offsets[threadIdx.x * count_stride + blockIdx.x];
+        for (int r = 0; r < BIN_ROUNDS; r++)
+            for (int w = 0; w < BLOCK / 64; w++) {
+                uint32_t v = counts[r][w][threadIdx.x];
+                counts[r][w][threadIdx.x] = running;
+                running += v;
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < BIN_ROUNDS; r++)
+        if (classes[r] >= 0) list_out[counts[r][wave][classes[r]] + below[r]] = slots[r];
 }
 
 // -------------------------------------------------------------------------------------------------
 // Loop body of raytrace (app/pathtracer.cpp:69-171) for the paths of one class.
 template<int CLS>
-__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, BatchParams b, PathPool in, PathPool out, HitRecords hits,
-                                                 const uint32_t* queue, BounceCounters* counters, ShadowQueue shadow,
-                                                 SampleResults res) {
-    const uint32_t n = counters->queue_count[CLS];
-    const uint32_t rounds = (n + gridDim.x * BLOCK - 1) / (gridDim.x * BLOCK);
-    for (uint32_t r = 0; r < rounds; r++) {
-        const uint32_t qi = (r * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x;
-        const bool valid = qi < n;
-        bool alive = false, want_shadow = false;
-        // next state
-        V3 n_org{}, n_dir{}, thr{}, saved{};
-        double scatter_pdf = 0;
-        uint32_t sid = 0, n_flags = 0;
-        Rng rng{0, 0};
-        // shadow record
-        V3 sh_dir{}, sh_contrib{};
-        double sh_dist = 0;
-        uint64_t sh_key = 0;
+__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, BatchParams b, PathState ps, const uint32_t* list, const BinInfo* info) {
+    const uint32_t n = info->count[CLS];
+    const uint32_t first = info->start[CLS];
+    for (uint32_t qi = blockIdx.x * BLOCK + threadIdx.x; qi < n; qi += gridDim.x * BLOCK) {
+        const uint32_t slot = list[first + qi];
+        V3 org = v3(ps.ox[slot], ps.oy[slot], ps.oz[slot]);
+        V3 dir = v3(ps.dx[slot], ps.dy[slot], ps.dz[slot]);
+        V3 thr = v3(ps.tx[slot], ps.ty[slot], ps.tz[slot]);
+        V3 saved = v3(ps.sx[slot], ps.sy[slot], ps.sz[slot]);
+        double scatter_pdf = ps.spdf[slot];
+        const uint32_t flags = ps.flags[slot];
+        const uint32_t depth = flags & DEPTH_MASK;
+        uint32_t ray_type = (flags >> TYPE_SHIFT) & 3u;
+        bool has_hit = (flags & FLAG_HAS_HIT) != 0;
+        uint32_t medium = flags >> 16;
+        if (medium == MEDIUM_NONE) medium = static_cast<uint32_t>(sc.background_medium);
+        const DevMedium& med = sc.media[medium];
+        uint32_t pixel, sample;
+        sample_coordinates(b, slot, pixel, sample);
+        Rng rng{rng_key(b.seed, pixel, sample), ps.ctr[slot]};
+        if (med.type == PTK_MEDIUM_HOMOGENEOUS_SCATTERING) {
+            // the numbers k_extend drew for the free-flight distance: the channel, and the
+            // distance only when that channel attenuates (src/medium.cpp:45-51)
+            int channel = rng.integer(0, 3);
+            if (med.extinction[channel] != 0) rng.ctr++;
+        }
+        const double t = ps.hit_t[slot];
+        const V3 point = org + dir * t;
+        int next_medium = static_cast<int>(medium);
+        V3 n_dir;
         uint32_t sh_info = 0;
 
-        if (valid) {
-            const uint32_t slot = queue[qi];
-            V3 org = v3(in.ox[slot], in.oy[slot], in.oz[slot]);
-            V3 dir = v3(in.dx[slot], in.dy[slot], in.dz[slot]);
-            thr = v3(in.tx[slot], in.ty[slot], in.tz[slot]);
-            saved = v3(in.sx[slot], in.sy[slot], in.sz[slot]);
-            scatter_pdf = in.spdf[slot];
-            sid = in.sid[slot];
-            const uint32_t flags = in.flags[slot];
-            const uint32_t depth = flags & DEPTH_MASK;
-            uint32_t ray_type = (flags >> TYPE_SHIFT) & 3u;
-            bool has_hit = (flags & FLAG_HAS_HIT) != 0;
-            uint32_t medium = flags >> 16;
-            if (medium == MEDIUM_NONE) medium = static_cast<uint32_t>(sc.background_medium);
-            const DevMedium& med = sc.media[medium];
-            uint32_t pixel, sample;
-            sample_coordinates(b, sid, pixel, sample);
-            rng.key = rng_key(b.seed, pixel, sample);
-            rng.ctr = in.ctr[slot];
-            if (med.type == PTK_MEDIUM_HOMOGENEOUS_SCATTERING) {
-                // the numbers k_extend drew for the free-flight distance: the channel, and the
-                // distance only when that channel attenuates (src/medium.cpp:45-51)
-                int channel = rng.integer(0, 3);
-                if (med.extinction[channel] != 0) rng.ctr++;
+        if (CLS == CLASS_SCATTER) {
+            // :71-93
+            V3 emission = medium_emission(med) * thr;
+            if (emission.x != 0 || emission.y != 0 || emission.z != 0) {
+                ps.cr[slot] += emission.x;
+                ps.cg[slot] += emission.y;
+                ps.cb[slot] += emission.z;
             }
-
-            const double t = hits.t[slot];
-            const V3 point = org + dir * t;
-            int next_medium = static_cast<int>(medium);
-
-            if (CLS == CLASS_SCATTER) {
-                // :71-93
-                V3 emission = medium_emission(med) * thr;
-                if (emission.x != 0 || emission.y != 0 || emission.z != 0) {
-                    res.cr[sid] += emission.x;
-                    res.cg[sid] += emission.y;
-                    res.cb[sid] += emission.z;
+            thr = thr * medium_sample_weight(med, t, true);
+            n_dir = sample_spherical(rng);
+            if (sc.nee) {
+                LightSample ls;
+                if (pick_light_point(sc, -1, point, ls, rng)) {
+                    double weight = mis_weight(ls.light_pdf, PHASE_ISOTROPIC);
+                    V3 contrib = thr * (weight * PHASE_ISOTROPIC / ls.light_pdf * static_cast<double>(sc.n_lights));
+                    ps.sh_dx[slot] = ls.direction.x;
+                    ps.sh_dy[slot] = ls.direction.y;
+                    ps.sh_dz[slot] = ls.direction.z;
+                    ps.sh_dist[slot] = ls.distance;
+                    ps.sh_cr[slot] = contrib.x;
+                    ps.sh_cg[slot] = contrib.y;
+                    ps.sh_cb[slot] = contrib.z;
+                    ps.sh_key[slot] = rng_fork(rng.key, rng.ctr);
+                    rng.ctr++;
+                    sh_info = SHADOW_VALID | static_cast<uint32_t>(ls.light_index) | (medium << 16);
                 }
-                thr = thr * medium_sample_weight(med, t, true);
-                V3 scattered = sample_spherical(rng);
-                if (sc.nee) {
-                    LightSample ls;
-                    if (pick_light_point(sc, -1, point, ls, rng)) {
-                        double weight = mis_weight(ls.light_pdf, PHASE_ISOTROPIC);
-                        sh_contrib = thr * (weight * PHASE_ISOTROPIC / ls.light_pdf * static_cast<double>(sc.n_lights));
-                        sh_dir = ls.direction;
-                        sh_dist = ls.distance;
-                        sh_key = rng_fork(rng.key, rng.ctr);
+                ray_type = RAY_DIFFUSE;
+                scatter_pdf = PHASE_ISOTROPIC;
+                saved = point;
+            }
+        }
+        else {
+            // :94-155
+            thr = thr * medium_sample_weight(med, t, false);
+            const int obj = ps.hit_obj[slot];
+            const int prim = ps.hit_prim[slot];
+            const DevObject& o = sc.objects[obj];
+            const DevMaterial& m = sc.materials[o.material];
+            Surface s;
+            s.point = point;
+            s.incident = dir;
+            s.obj = obj;
+            s.prim = prim;
+            V3 normal = object_normal(sc, o, point, prim);
+            s.outside = dot(dir, normal) < 0;
+            s.normal = s.outside ? normal : -normal;
+            s.use_uv = m.needs_uv != 0;
+            s.u = s.v = 0;
+            if (s.use_uv) object_uv(sc, o, point, prim, s.u, s.v);
+
+            if (!has_hit) {
+                ps.px[slot] = point.x;
+                ps.py[slot] = point.y;
+                ps.pz[slot] = point.z;
+                ps.nx[slot] = s.normal.x;
+                ps.ny[slot] = s.normal.y;
+                ps.nz[slot] = s.normal.z;
+                has_hit = true;
+            }
+            const bool is_specular = ray_type == RAY_REFLECTED || ray_type == RAY_TRANSMITTED;
+            if (m.is_light) { // :106-119
+                double weight = 1;
+                if (sc.nee && depth != 0 && !is_specular)
+                    weight = mis_weight(scatter_pdf, object_light_pdf(sc, o, point, saved, prim));
+                V3 add = material_emittance(sc, m, s.use_uv, s.u, s.v) * weight * thr;
+                ps.cr[slot] += add.x;
+                ps.cg[slot] += add.y;
+                ps.cb[slot] += add.z;
+            }
+            if (sc.nee) { // sample_light up to the march (src/objects.cpp:515-551, 562-578)
+                LightSample ls;
+                if (pick_light_point(sc, obj, point, ls, rng)) {
+                    V3 brdf = material_eval<CLS>(sc, m, s, ls.direction, rng);
+                    if (len2(brdf) != 0) {
+                        double pdf = material_pdf<CLS>(sc, m, s, ls.direction);
+                        const uint64_t key = rng_fork(rng.key, rng.ctr);
                         rng.ctr++;
-                        sh_info = static_cast<uint32_t>(ls.light_index) | (medium << 16);
-                        want_shadow = true;
-                    }
-                    ray_type = RAY_DIFFUSE;
-                    scatter_pdf = PHASE_ISOTROPIC;
-                    saved = point;
-                }
-                n_org = point;
-                n_dir = scattered;
-            }
-            else {
-                // :94-155
-                thr = thr * medium_sample_weight(med, t, false);
-                const int obj = hits.obj[slot];
-                const int prim = hits.prim[slot];
-                const DevObject& o = sc.objects[obj];
-                const DevMaterial& m = sc.materials[o.material];
-                Surface s;
-                s.point = point;
-                s.incident = dir;
-                s.obj = obj;
-                s.prim = prim;
-                V3 normal = object_normal(sc, o, point, prim);
-                s.outside = dot(dir, normal) < 0;
-                s.normal = s.outside ? normal : -normal;
-                s.use_uv = m.needs_uv != 0;
-                s.u = s.v = 0;
-                if (s.use_uv) object_uv(sc, o, point, prim, s.u, s.v);
-
-                if (!has_hit) {
-                    res.px[sid] = point.x;
-                    res.py[sid] = point.y;
-                    res.pz[sid] = point.z;
-                    res.nx[sid] = s.normal.x;
-                    res.ny[sid] = s.normal.y;
-                    res.nz[sid] = s.normal.z;
-                    has_hit = true;
-                }
-                const bool is_specular = ray_type == RAY_REFLECTED || ray_type == RAY_TRANSMITTED;
-                if (m.is_light) { // :106-119
-                    double weight = 1;
-                    if (sc.nee && depth != 0 && !is_specular)
-                        weight = mis_weight(scatter_pdf, object_light_pdf(sc, o, point, saved, prim));
-                    V3 add = material_emittance(sc, m, s.use_uv, s.u, s.v) * weight * thr;
-                    res.cr[sid] += add.x;
-                    res.cg[sid] += add.y;
-                    res.cb[sid] += add.z;
-                }
-                if (sc.nee) { // sample_light up to the march (src/objects.cpp:515-551, 562-578)
-                    LightSample ls;
-                    if (pick_light_point(sc, obj, point, ls, rng)) {
-                        V3 brdf = material_eval<CLS>(sc, m, s, ls.direction, rng);
-                        if (len2(brdf) != 0) {
-                            double pdf = material_pdf<CLS>(sc, m, s, ls.direction);
-                            sh_key = rng_fork(rng.key, rng.ctr);
-                            rng.ctr++;
-                            bool wrong_side = dot(s.incident, s.normal) * dot(ls.direction, s.normal) > 0;
-                            double cosine = fmax(dot(s.normal, ls.direction), 0.0);
-                            if (!wrong_side && cosine > 0) {
-                                double weight = mis_weight(ls.light_pdf, pdf);
-                                sh_contrib = brdf * thr * (weight * cosine / ls.light_pdf * static_cast<double>(sc.n_lights));
-                                sh_dir = ls.direction;
-                                sh_dist = ls.distance;
-                                sh_info = static_cast<uint32_t>(ls.light_index) | (medium << 16);
-                                want_shadow = true;
-                            }
+                        bool wrong_side = dot(s.incident, s.normal) * dot(ls.direction, s.normal) > 0;
+                        double cosine = fmax(dot(s.normal, ls.direction), 0.0);
+                        if (!wrong_side && cosine > 0) {
+                            double weight = mis_weight(ls.light_pdf, pdf);
+                            V3 contrib = brdf * thr * (weight * cosine / ls.light_pdf * static_cast<double>(sc.n_lights));
+                            ps.sh_dx[slot] = ls.direction.x;
+                            ps.sh_dy[slot] = ls.direction.y;
+                            ps.sh_dz[slot] = ls.direction.z;
+                            ps.sh_dist[slot] = ls.distance;
+                            ps.sh_cr[slot] = contrib.x;
+                            ps.sh_cg[slot] = contrib.y;
+                            ps.sh_cb[slot] = contrib.z;
+                            ps.sh_key[slot] = key;
+                            sh_info = SHADOW_VALID | static_cast<uint32_t>(ls.light_index) | (medium << 16);
                         }
                     }
                 }
-                BrdfSample bs = material_sample<CLS>(sc, m, s, rng); // :126-137
-                bool is_virtual = allow_direct_light(sc, m, s, rng);
-                if (is_virtual) {
-                    bs.type = ray_type;
-                }
-                else {
-                    scatter_pdf = bs.pdf;
-                    saved = point;
-                }
-                thr = thr * bs.weight;
-                if (dot(s.incident, s.normal) * dot(bs.outgoing, s.normal) > 0) // :139-151
-                    next_medium = s.outside ? m.internal_medium : m.external_medium;
-                n_org = point;
-                n_dir = bs.outgoing;
-                ray_type = bs.type;
             }
-
-            // Russian roulette :157-171
-            bool allow = true;
-            if (static_cast<int>(depth) >= sc.min_depth) {
-                double threshold = fmin(vmax(thr), 0.9);
-                allow = rng.u01() < threshold;
-                if (allow) thr = thr / threshold;
+            BrdfSample bs = material_sample<CLS>(sc, m, s, rng); // :126-137
+            bool is_virtual = allow_direct_light(sc, m, s, rng);
+            if (is_virtual) {
+                bs.type = ray_type;
             }
-            alive = allow && static_cast<int>(depth) + 1 <= sc.max_depth;
-            n_flags = (depth + 1) | (ray_type << TYPE_SHIFT) | (has_hit ? FLAG_HAS_HIT : 0u) |
-                      ((next_medium < 0 ? MEDIUM_NONE : static_cast<uint32_t>(next_medium)) << 16);
+            else {
+                scatter_pdf = bs.pdf;
+                saved = point;
+            }
+            thr = thr * bs.weight;
+            if (dot(s.incident, s.normal) * dot(bs.outgoing, s.normal) > 0) // :139-151
+                next_medium = s.outside ? m.internal_medium : m.external_medium;
+            n_dir = bs.outgoing;
+            ray_type = bs.type;
         }
 
-        const uint32_t shadow_pos = wave_append(&counters->n_shadow, want_shadow);
-        if (want_shadow) {
-            shadow.ox[shadow_pos] = n_org.x;
-            shadow.oy[shadow_pos] = n_org.y;
-            shadow.oz[shadow_pos] = n_org.z;
-            shadow.dx[shadow_pos] = sh_dir.x;
-            shadow.dy[shadow_pos] = sh_dir.y;
-            shadow.dz[shadow_pos] = sh_dir.z;
-            shadow.dist[shadow_pos] = sh_dist;
-            shadow.cr[shadow_pos] = sh_contrib.x;
-            shadow.cg[shadow_pos] = sh_contrib.y;
-            shadow.cb[shadow_pos] = sh_contrib.z;
-            shadow.key[shadow_pos] = sh_key;
-            shadow.sid[shadow_pos] = sid;
-            shadow.info[shadow_pos] = sh_info;
+        // Russian roulette :157-171
+        bool allow = true;
+        if (static_cast<int>(depth) >= sc.min_depth) {
+            double threshold = fmin(vmax(thr), 0.9);
+            allow = rng.u01() < threshold;
+            if (allow) thr = thr / threshold;
         }
-        const uint32_t next = wave_append(&counters->n_next, alive);
+        const bool alive = allow && static_cast<int>(depth) + 1 <= sc.max_depth;
+
+        ps.sh_info[slot] = sh_info;
+        ps.ox[slot] = point.x; // the new ray's origin, and the origin of the pending shadow ray
+        ps.oy[slot] = point.y;
+        ps.oz[slot] = point.z;
         if (alive) {
-            out.ox[next] = n_org.x;
-            out.oy[next] = n_org.y;
-            out.oz[next] = n_org.z;
-            out.dx[next] = n_dir.x;
-            out.dy[next] = n_dir.y;
-            out.dz[next] = n_dir.z;
-            out.tx[next] = thr.x;
-            out.ty[next] = thr.y;
-            out.tz[next] = thr.z;
-            out.sx[next] = saved.x;
-            out.sy[next] = saved.y;
-            out.sz[next] = saved.z;
-            out.spdf[next] = scatter_pdf;
-            out.sid[next] = sid;
-            out.ctr[next] = rng.ctr;
-            out.flags[next] = n_flags;
+            ps.dx[slot] = n_dir.x;
+            ps.dy[slot] = n_dir.y;
+            ps.dz[slot] = n_dir.z;
+            ps.tx[slot] = thr.x;
+            ps.ty[slot] = thr.y;
+            ps.tz[slot] = thr.z;
+            ps.sx[slot] = saved.x;
+            ps.sy[slot] = saved.y;
+            ps.sz[slot] = saved.z;
+            ps.spdf[slot] = scatter_pdf;
+            ps.ctr[slot] = rng.ctr;
+            ps.flags[slot] = (depth + 1) | (ray_type << TYPE_SHIFT) | (has_hit ? FLAG_HAS_HIT : 0u) |
+                             ((next_medium < 0 ? MEDIUM_NONE : static_cast<uint32_t>(next_medium)) << 16);
+        }
+        else {
+            ps.cls[slot] = CLASS_DEAD;
         }
     }
 }
 
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_connect(DevScene sc, ShadowQueue shadow, const BounceCounters* counters,
-                                                   SampleResults res, unsigned long long* ray_counter) {
+// Visibility march for every path of the bounce's list that has a pending connection.
+__global__ __launch_bounds__(BLOCK) void k_connect(DevScene sc, PathState ps, const uint32_t* list, const BinInfo* info,
+                                                   unsigned long long* ray_counter) {
     __shared__ StackEntry lds_stack[LDS_STACK_DEPTH * BLOCK];
+    __shared__ uint32_t block_rays;
     TraversalStack st = make_stack(lds_stack);
-    const uint32_t n = counters->n_shadow;
+    if (threadIdx.x == 0) block_rays = 0;
+    __syncthreads();
+    const uint32_t n = info->total;
     uint32_t rays = 0;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
-        V3 org = v3(shadow.ox[i], shadow.oy[i], shadow.oz[i]);
-        V3 dir = v3(shadow.dx[i], shadow.dy[i], shadow.dz[i]);
-        const uint32_t info = shadow.info[i];
-        uint32_t medium = info >> 16;
-        Rng rng{shadow.key[i], 0};
-        V3 visible = march_to_light(sc, org, dir, static_cast<int>(medium), static_cast<int>(info & 0xFFFFu), shadow.dist[i],
-                                    rng, st, rays);
+        const uint32_t slot = list[i];
+        const uint32_t sh = ps.sh_info[slot];
+        if (!(sh & SHADOW_VALID)) continue;
+        V3 org = v3(ps.ox[slot], ps.oy[slot], ps.oz[slot]);
+        V3 dir = v3(ps.sh_dx[slot], ps.sh_dy[slot], ps.sh_dz[slot]);
+        uint32_t medium = (sh >> 16) & 0x7FFFu;
+        Rng rng{ps.sh_key[slot], 0};
+        V3 visible = march_to_light(sc, org, dir, static_cast<int>(medium), static_cast<int>(sh & 0xFFFFu), ps.sh_dist[slot], rng,
+                                    st, rays);
         if (visible.x != 0 || visible.y != 0 || visible.z != 0) {
-            const uint32_t sid = shadow.sid[i];
-            res.cr[sid] += shadow.cr[i] * visible.x;
-            res.cg[sid] += shadow.cg[i] * visible.y;
-            res.cb[sid] += shadow.cb[i] * visible.z;
+            ps.cr[slot] += ps.sh_cr[slot] * visible.x;
+            ps.cg[slot] += ps.sh_cg[slot] * visible.y;
+            ps.cb[slot] += ps.sh_cb[slot] * visible.z;
         }
     }
-    // shadow-ray count for the statistics: one atomic per wave
+    // shadow-ray count for the statistics: one global atomic per block
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
-    if (__lane_id() == 0 && rays) atomicAdd(ray_counter, static_cast<unsigned long long>(rays));
+    if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&block_rays, rays);
+    __syncthreads();
+    if (threadIdx.x == 0 && block_rays) atomicAdd(ray_counter, static_cast<unsigned long long>(block_rays));
 }
 
 // -------------------------------------------------------------------------------------------------
 // compute_pixel_color's mean over the batch's samples (app/pathtracer.cpp:192-199) and
 // raytrace_section's running mean (:232-235, 253-267); one lane per pixel, samples in order.
-__global__ __launch_bounds__(BLOCK) void k_accumulate(BatchParams b, SampleResults res, double* image, double* position,
+__global__ __launch_bounds__(BLOCK) void k_accumulate(BatchParams b, PathState res, double* image, double* position,
                                                       double* normal, unsigned long long* pixel_counters) {
     for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < b.n_pixels; p += gridDim.x * BLOCK) {
         double sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -457,7 +546,7 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(BatchParams b, SampleResul
 }
 
 // Copies per-sample results to [pixel][sample][3] host-order arrays (ptk_trace_samples).
-__global__ __launch_bounds__(BLOCK) void k_gather_samples(BatchParams b, SampleResults res, size_t pixel_base,
+__global__ __launch_bounds__(BLOCK) void k_gather_samples(BatchParams b, PathState res, size_t pixel_base,
                                                           double* color, double* position, double* normal) {
     for (uint32_t sid = blockIdx.x * BLOCK + threadIdx.x; sid < b.n_paths; sid += gridDim.x * BLOCK) {
         uint32_t s = sid / b.n_pixels, p = sid - s * b.n_pixels;
@@ -523,56 +612,64 @@ static inline uint32_t grid_for(uint32_t n, uint32_t max_blocks) {
     return g < max_blocks ? g : max_blocks;
 }
 
-void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathPool& pool, const SampleResults& res) {
-    hipLaunchKernelGGL(k_generate, dim3(grid_for(b.n_paths, 4096)), dim3(BLOCK), 0, s, sc, b, pool, res);
+uint32_t bin_blocks(uint32_t n) {
+    return n == 0 ? 1u : (n + BIN_CHUNK - 1) / BIN_CHUNK;
 }
 
-void launch_extend(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathPool& pool, uint32_t n_active,
-                   const HitRecords& hits, uint32_t* queues, uint32_t queue_stride, BounceCounters* counters,
-                   const SampleResults& res) {
-    hipLaunchKernelGGL(k_extend, dim3(grid_for(n_active, 8192)), dim3(BLOCK), 0, s, sc, b, pool, n_active, hits, queues,
-                       queue_stride, counters, res);
+void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathState& ps, uint32_t* list) {
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(b.n_paths, 4096)), dim3(BLOCK), 0, s, sc, b, ps, list);
+}
+
+void launch_extend(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathState& ps, const uint32_t* list, uint32_t n,
+                   uint32_t* block_counts, uint32_t count_stride, unsigned long long* ray_counter) {
+    hipLaunchKernelGGL(k_extend, dim3(bin_blocks(n)), dim3(BLOCK), 0, s, sc, b, ps, list, n, block_counts, count_stride,
+                       ray_counter);
+}
+
+void launch_bin(hipStream_t s, const DevScene& sc, const PathState& ps, const uint32_t* list_in, uint32_t n, uint32_t* block_counts,
+                uint32_t count_stride, BinInfo* info, uint32_t* list_out) {
+    const uint32_t blocks = bin_blocks(n);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, block_counts, count_stride, blocks, info);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(blocks), dim3(BLOCK), 0, s, ps, list_in, n, block_counts, count_stride, sc.class_mask,
+                       list_out);
 }
 
 template<int CLS>
-static void launch_shade_t(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in,
-                           const PathPool& out, const HitRecords& hits, const uint32_t* queue, BounceCounters* counters,
-                           const ShadowQueue& shadow, const SampleResults& res) {
-    hipLaunchKernelGGL(k_shade<CLS>, dim3(grid_for(bound, 8192)), dim3(BLOCK), 0, s, sc, b, in, out, hits, queue, counters,
-                       shadow, res);
+static void launch_shade_t(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathState& ps,
+                           const uint32_t* list, const BinInfo* info) {
+    hipLaunchKernelGGL(k_shade<CLS>, dim3(grid_for(bound, 16384)), dim3(BLOCK), 0, s, sc, b, ps, list, info);
 }
 
-void launch_shade(hipStream_t s, int cls, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in,
-                  const PathPool& out, const HitRecords& hits, const uint32_t* queue, BounceCounters* counters,
-                  const ShadowQueue& shadow, const SampleResults& res) {
+void launch_shade(hipStream_t s, int cls, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathState& ps,
+                  const uint32_t* list, const BinInfo* info) {
     switch (cls) {
-        case 0: launch_shade_t<0>(s, bound, sc, b, in, out, hits, queue, counters, shadow, res); break;
-        case 1: launch_shade_t<1>(s, bound, sc, b, in, out, hits, queue, counters, shadow, res); break;
-        case 2: launch_shade_t<2>(s, bound, sc, b, in, out, hits, queue, counters, shadow, res); break;
-        case 3: launch_shade_t<3>(s, bound, sc, b, in, out, hits, queue, counters, shadow, res); break;
-        case 4: launch_shade_t<4>(s, bound, sc, b, in, out, hits, queue, counters, shadow, res); break;
-        case 5: launch_shade_t<5>(s, bound, sc, b, in, out, hits, queue, counters, shadow, res); break;
-        case 6: launch_shade_t<6>(s, bound, sc, b, in, out, hits, queue, counters, shadow, res); break;
-        case 7: launch_shade_t<7>(s, bound, sc, b, in, out, hits, queue, counters, shadow, res); break;
+        case 0: launch_shade_t<0>(s, bound, sc, b, ps, list, info); break;
+        case 1: launch_shade_t<1>(s, bound, sc, b, ps, list, info); break;
+        case 2: launch_shade_t<2>(s, bound, sc, b, ps, list, info); break;
+        case 3: launch_shade_t<3>(s, bound, sc, b, ps, list, info); break;
+        case 4: launch_shade_t<4>(s, bound, sc, b, ps, list, info); break;
+        case 5: launch_shade_t<5>(s, bound, sc, b, ps, list, info); break;
+        case 6: launch_shade_t<6>(s, bound, sc, b, ps, list, info); break;
+        case 7: launch_shade_t<7>(s, bound, sc, b, ps, list, info); break;
         default: break;
     }
 }
 
-void launch_connect(hipStream_t s, uint32_t bound, const DevScene& sc, const ShadowQueue& shadow, const BounceCounters* counters,
-                    const SampleResults& res, unsigned long long* ray_counter) {
-    hipLaunchKernelGGL(k_connect, dim3(grid_for(bound, 8192)), dim3(BLOCK), 0, s, sc, shadow, counters, res, ray_counter);
+void launch_connect(hipStream_t s, uint32_t bound, const DevScene& sc, const PathState& ps, const uint32_t* list, const BinInfo* info,
+                    unsigned long long* ray_counter) {
+    hipLaunchKernelGGL(k_connect, dim3(grid_for(bound, 16384)), dim3(BLOCK), 0, s, sc, ps, list, info, ray_counter);
 }
 
-void launch_accumulate(hipStream_t s, const BatchParams& b, const SampleResults& res, double* image, double* position,
-                       double* normal, unsigned long long* pixel_counters) {
-    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(b.n_pixels, 4096)), dim3(BLOCK), 0, s, b, res, image, position, normal,
+void launch_accumulate(hipStream_t s, const BatchParams& b, const PathState& ps, double* image, double* position, double* normal,
+                       unsigned long long* pixel_counters) {
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(b.n_pixels, 4096)), dim3(BLOCK), 0, s, b, ps, image, position, normal,
                        pixel_counters);
 }
 
-void launch_gather_samples(hipStream_t s, const BatchParams& b, const SampleResults& res, size_t pixel_base, double* color,
+void launch_gather_samples(hipStream_t s, const BatchParams& b, const PathState& ps, size_t pixel_base, double* color,
                            double* position, double* normal) {
-    hipLaunchKernelGGL(k_gather_samples, dim3(grid_for(b.n_paths, 4096)), dim3(BLOCK), 0, s, b, res, pixel_base, color,
-                       position, normal);
+    hipLaunchKernelGGL(k_gather_samples, dim3(grid_for(b.n_paths, 4096)), dim3(BLOCK), 0, s, b, ps, pixel_base, color, position,
+                       normal);
 }
 
 void launch_primary(hipStream_t s, const DevScene& sc, const BatchParams& b, int32_t* object_index, int32_t* primitive_index,

@@ -115,42 +115,39 @@ struct DevScene {
     uint32_t class_mask;                 // material classes present in the scene (+ scatter bit)
 };
 
-// Path state, structure of arrays, `capacity` slots.
-struct PathPool {
+// Path state: structure of arrays with one entry per sample of the batch.  The index of a sample,
+// sid = sample * pixels_in_batch + pixel, is also its slot for the whole life of the path: nothing
+// is ever moved.  Kernels reach the live paths through index lists (see kernels.hip).
+struct PathState {
     double *ox, *oy, *oz;   // ray origin
     double *dx, *dy, *dz;   // ray direction
     double *tx, *ty, *tz;   // throughput
     double *sx, *sy, *sz;   // saved_point (origin of the last non-virtual sampling event)
     double *spdf;           // scatter_pdf of that event
-    uint32_t* sid;          // batch index of the sample
     uint32_t* ctr;          // next random-number counter
-    uint32_t* flags;        // depth (13 bits) | ray type << 13 | has_hit_surface << 15 | medium << 16 (0xFFFF = none)
+    uint32_t* flags;        // depth (13 bits) | ray type << 13 | has_hit_surface << 15 | medium << 16
+    // hit record: written by k_extend, read by k_shade
+    double* hit_t;          // distance to the vertex (surface hit or scatter point)
+    int32_t* hit_obj;       // object index
+    int32_t* hit_prim;      // triangle index (global, leaf order) for triangles / meshes
+    uint8_t* cls;           // queue class of the current vertex; CLASS_DEAD once the path has ended
+    // pending next-event connection: written by k_shade, consumed by k_connect (origin = ox, oy, oz)
+    double *sh_dx, *sh_dy, *sh_dz;
+    double* sh_dist;           // distance to the sampled light point
+    double *sh_cr, *sh_cg, *sh_cb; // contribution before emittance and transmittance
+    uint64_t* sh_key;          // forked random-number key for the march
+    uint32_t* sh_info;         // SHADOW_VALID | medium << 16 | light object index
+    // results (PixelData, app/pathtracer.cpp:20-24)
+    double *cr, *cg, *cb;      // radiance
+    double *px, *py, *pz;      // first-surface position
+    double *nx, *ny, *nz;      // first-surface normal
 };
 constexpr uint32_t DEPTH_MASK = 0x1FFFu;
 constexpr uint32_t TYPE_SHIFT = 13;
 constexpr uint32_t FLAG_HAS_HIT = 1u << 15;
-constexpr uint32_t MEDIUM_NONE = 0xFFFFu;
-
-struct HitRecords { // written by extend, read by shade; indexed by slot
-    double* t;      // distance to the vertex (surface hit or scatter point)
-    int32_t* obj;   // object index
-    int32_t* prim;  // triangle index (global, leaf order) for triangles / meshes
-};
-
-struct ShadowQueue { // next-event connections awaiting their visibility march
-    double *ox, *oy, *oz, *dx, *dy, *dz;
-    double* dist;             // distance to the sampled light point
-    double *cr, *cg, *cb;     // contribution before emittance and transmittance
-    uint64_t* key;            // forked random-number key for the march
-    uint32_t* sid;
-    uint32_t* info;           // light object index | medium << 16
-};
-
-struct SampleResults { // per sample of the batch
-    double *cr, *cg, *cb;     // radiance
-    double *px, *py, *pz;     // first-surface position
-    double *nx, *ny, *nz;     // first-surface normal
-};
+constexpr uint32_t MEDIUM_NONE = 0x7FFFu;
+constexpr uint32_t SHADOW_VALID = 1u << 31;
+constexpr uint8_t CLASS_DEAD = 0xFF;
 
 struct BatchParams {
     int64_t start_idx;    // first pixel
@@ -161,12 +158,17 @@ struct BatchParams {
     uint64_t seed;
 };
 
-// device counters for one bounce
-struct BounceCounters {
-    uint32_t queue_count[N_CLASSES];
-    uint32_t n_shadow;
-    uint32_t n_next;      // survivors written to the other pool
-    uint32_t _pad[6];
+// A bounce's list of live paths is binned by class without atomics: k_extend leaves per-block
+// class counts, k_bin_scan turns them into offsets (and this summary), k_bin_scatter writes the
+// class-sorted list.  BIN_CHUNK consecutive list entries belong to one block in all three.
+constexpr int BIN_BLOCK = 256;
+constexpr int BIN_ROUNDS = 8;
+constexpr int BIN_CHUNK = BIN_BLOCK * BIN_ROUNDS;
+struct BinInfo {
+    uint32_t start[N_CLASSES]; // first entry of each class segment in the sorted list
+    uint32_t count[N_CLASSES];
+    uint32_t total;            // live paths = length of the sorted list
+    uint32_t _pad[15];
 };
 
 } // namespace ptk

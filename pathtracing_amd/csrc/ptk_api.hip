@@ -163,13 +163,12 @@ struct PtkScene {
     DeviceBuffers pool_buffers;  // path state, queues, results
     int64_t max_paths = DEFAULT_MAX_PATHS;
     int64_t capacity = 0;
-    PathPool pool[2]{};
-    HitRecords hits{};
-    uint32_t* queues = nullptr; // [N_CLASSES][capacity]
-    ShadowQueue shadow{};
-    SampleResults results{};
-    BounceCounters* d_counters = nullptr;
-    BounceCounters* h_counters = nullptr; // pinned
+    PathState state{};
+    uint32_t* lists[2] = {nullptr, nullptr}; // ping-pong index lists of live paths
+    uint32_t* block_counts = nullptr;        // [N_CLASSES][count_stride]
+    uint32_t count_stride = 0;
+    BinInfo* d_info = nullptr;
+    BinInfo* h_info = nullptr; // pinned
     unsigned long long* d_ray_counter = nullptr;
     std::vector<int> classes; // queue classes present in the scene
     PtkFilm* host_film = nullptr; // scratch film for ptk_render_host
@@ -181,46 +180,39 @@ namespace {
 
 int ensure_capacity(PtkScene* s, int64_t paths) {
     if (paths <= s->capacity) return PTK_OK;
-    s->pool_buffers.free_all(); // the previous, smaller pools
+    s->pool_buffers.free_all(); // the previous, smaller arrays
     s->capacity = 0;
     const size_t n = static_cast<size_t>(paths);
     DeviceBuffers& b = s->pool_buffers;
-    for (int k = 0; k < 2; k++) {
-        PathPool& p = s->pool[k];
-        double** fields[] = {&p.ox, &p.oy, &p.oz, &p.dx, &p.dy, &p.dz, &p.tx, &p.ty, &p.tz, &p.sx, &p.sy, &p.sz, &p.spdf};
-        for (double** f : fields) HIP_TRY(b.alloc(f, n));
-        HIP_TRY(b.alloc(&p.sid, n));
-        HIP_TRY(b.alloc(&p.ctr, n));
-        HIP_TRY(b.alloc(&p.flags, n));
-    }
-    HIP_TRY(b.alloc(&s->hits.t, n));
-    HIP_TRY(b.alloc(&s->hits.obj, n));
-    HIP_TRY(b.alloc(&s->hits.prim, n));
-    HIP_TRY(b.alloc(&s->queues, n * N_CLASSES));
-    {
-        ShadowQueue& q = s->shadow;
-        double** fields[] = {&q.ox, &q.oy, &q.oz, &q.dx, &q.dy, &q.dz, &q.dist, &q.cr, &q.cg, &q.cb};
-        for (double** f : fields) HIP_TRY(b.alloc(f, n));
-        HIP_TRY(b.alloc(&q.key, n));
-        HIP_TRY(b.alloc(&q.sid, n));
-        HIP_TRY(b.alloc(&q.info, n));
-    }
-    {
-        SampleResults& r = s->results;
-        double** fields[] = {&r.cr, &r.cg, &r.cb, &r.px, &r.py, &r.pz, &r.nx, &r.ny, &r.nz};
-        for (double** f : fields) HIP_TRY(b.alloc(f, n));
-    }
+    PathState& p = s->state;
+    double** doubles[] = {&p.ox, &p.oy, &p.oz, &p.dx, &p.dy, &p.dz, &p.tx, &p.ty, &p.tz, &p.sx, &p.sy, &p.sz, &p.spdf, &p.hit_t,
+                          &p.sh_dx, &p.sh_dy, &p.sh_dz, &p.sh_dist, &p.sh_cr, &p.sh_cg, &p.sh_cb, &p.cr, &p.cg, &p.cb, &p.px,
+                          &p.py, &p.pz, &p.nx, &p.ny, &p.nz};
+    for (double** f : doubles) HIP_TRY(b.alloc(f, n));
+    HIP_TRY(b.alloc(&p.ctr, n));
+    HIP_TRY(b.alloc(&p.flags, n));
+    HIP_TRY(b.alloc(&p.hit_obj, n));
+    HIP_TRY(b.alloc(&p.hit_prim, n));
+    HIP_TRY(b.alloc(&p.cls, n));
+    HIP_TRY(b.alloc(&p.sh_key, n));
+    HIP_TRY(b.alloc(&p.sh_info, n));
+    HIP_TRY(b.alloc(&s->lists[0], n));
+    HIP_TRY(b.alloc(&s->lists[1], n));
+    s->count_stride = bin_blocks(static_cast<uint32_t>(n));
+    HIP_TRY(b.alloc(&s->block_counts, static_cast<size_t>(s->count_stride) * N_CLASSES));
     s->capacity = paths;
     return PTK_OK;
 }
 
 // bytes the kernels are specified to move per item (path-state, hit, queue and shadow records)
-constexpr uint64_t EXTEND_BYTES_PER_PATH = 6 * 8 + 4 + 16 + 4;              // ray + flags in; hit record + queue index out
-constexpr uint64_t SHADE_BYTES_PER_PATH = (13 * 8 + 12) + 16 + 4;           // state + hit + queue index in
-constexpr uint64_t SHADE_BYTES_PER_SURVIVOR = 13 * 8 + 12;                  // state out
-constexpr uint64_t SHADE_BYTES_PER_SHADOW = 10 * 8 + 8 + 4 + 4;             // shadow record out
-constexpr uint64_t CONNECT_BYTES_PER_SHADOW = 10 * 8 + 8 + 4 + 4 + 2 * 24;  // record in + radiance read-modify-write
-constexpr uint64_t GENERATE_BYTES_PER_PATH = (13 * 8 + 12) + 9 * 8;         // state + zeroed results out
+constexpr uint64_t EXTEND_BYTES_PER_PATH = 4 + 1 + 6 * 8 + 4 + 16 + 1;      // list entry, class, ray, flags in; hit record + class out
+constexpr uint64_t BIN_BYTES_PER_PATH = 4 + 1 + 4;                          // list entry + class in, list entry out
+constexpr uint64_t SHADE_BYTES_PER_PATH = 4 + (13 * 8 + 8) + 16 + 3 * 8 + 4; // list entry, state, hit in; origin + shadow info out
+constexpr uint64_t SHADE_BYTES_PER_SURVIVOR = 10 * 8 + 8;                   // direction .. scatter pdf, counter, flags out
+constexpr uint64_t SHADE_BYTES_PER_SHADOW = 7 * 8 + 8;                      // shadow record out
+constexpr uint64_t CONNECT_BYTES_PER_PATH = 4 + 4;                          // list entry + shadow info in
+constexpr uint64_t CONNECT_BYTES_PER_SHADOW = 3 * 8 + 7 * 8 + 8 + 2 * 24;   // origin + record in, radiance read-modify-write
+constexpr uint64_t GENERATE_BYTES_PER_PATH = 13 * 8 + 8 + 1 + 4 + 9 * 8 + 4; // state, class, shadow info, zeroed results, list out
 constexpr uint64_t ACCUMULATE_BYTES_PER_PATH = 9 * 8;                       // results in
 
 struct EventTimer {
@@ -266,60 +258,63 @@ struct EventTimer {
 };
 
 // Traces one batch (all samples of a contiguous pixel range) to completion; per-sample results
-// are left in s->results.
+// are left in s->state.
 int trace_batch(PtkScene* s, const BatchParams& b) {
     EventTimer timer{s};
     PtkStats& st = s->stats;
     timer.begin(3);
-    launch_generate(g_stream, s->dev, b, s->pool[0], s->results);
+    launch_generate(g_stream, s->dev, b, s->state, s->lists[0]);
     timer.end();
     st.paths += b.n_paths;
     st.algorithmic_bytes += GENERATE_BYTES_PER_PATH * b.n_paths;
-    uint32_t n_active = b.n_paths;
+    uint32_t n = b.n_paths; // length of the current list (live paths, plus those the last shade ended)
     int cur = 0;
-    HIP_TRY(hipMemsetAsync(s->d_ray_counter, 0, sizeof(unsigned long long), g_stream));
-    for (int depth = 0; depth <= s->settings.max_recursion_depth && n_active > 0; depth++) {
-        HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(BounceCounters), g_stream));
+    const bool nee = s->settings.enable_next_event_estimation != 0;
+    HIP_TRY(hipMemsetAsync(s->d_ray_counter, 0, 2 * sizeof(unsigned long long), g_stream));
+    unsigned long long shadow_before = 0, extension_before = 0;
+    for (int depth = 0; depth <= s->settings.max_recursion_depth && n > 0; depth++) {
         timer.begin(0);
-        launch_extend(g_stream, s->dev, b, s->pool[cur], n_active, s->hits, s->queues, static_cast<uint32_t>(s->capacity),
-                      s->d_counters, s->results);
+        launch_extend(g_stream, s->dev, b, s->state, s->lists[cur], n, s->block_counts, s->count_stride, s->d_ray_counter + 1);
+        timer.end();
+        timer.begin(3);
+        launch_bin(g_stream, s->dev, s->state, s->lists[cur], n, s->block_counts, s->count_stride, s->d_info, s->lists[cur ^ 1]);
         timer.end();
         timer.begin(1);
-        for (int cls : s->classes)
-            launch_shade(g_stream, cls, n_active, s->dev, b, s->pool[cur], s->pool[cur ^ 1], s->hits,
-                         s->queues + static_cast<size_t>(cls) * static_cast<size_t>(s->capacity), s->d_counters, s->shadow,
-                         s->results);
+        for (int cls : s->classes) launch_shade(g_stream, cls, n, s->dev, b, s->state, s->lists[cur ^ 1], s->d_info);
         timer.end();
-        if (s->settings.enable_next_event_estimation) {
+        if (nee) {
             timer.begin(2);
-            launch_connect(g_stream, n_active, s->dev, s->shadow, s->d_counters, s->results, s->d_ray_counter);
+            launch_connect(g_stream, n, s->dev, s->state, s->lists[cur ^ 1], s->d_info, s->d_ray_counter);
             timer.end();
         }
-        HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, sizeof(BounceCounters), hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipMemcpyAsync(s->h_info, s->d_info, sizeof(BinInfo), hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipMemcpyAsync(&s->h_info->_pad[0], s->d_ray_counter, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, g_stream));
         HIP_TRY(hipStreamSynchronize(g_stream));
-        const BounceCounters& c = *s->h_counters;
-        uint64_t shaded = 0;
-        for (int k = 0; k < N_CLASSES; k++) shaded += c.queue_count[k];
-        st.extension_rays += n_active;
+        const BinInfo& c = *s->h_info;
+        unsigned long long ray_totals[2];
+        std::memcpy(ray_totals, &c._pad[0], sizeof(ray_totals));
+        const uint64_t shadows = ray_totals[0] - shadow_before; // closest-hit queries of this bounce's visibility marches
+        shadow_before = ray_totals[0];
+        st.extension_rays += ray_totals[1] - extension_before;
+        extension_before = ray_totals[1];
+        const uint64_t shaded = c.total;
         st.vertices += shaded;
         st.bounce_launch_rounds++;
         st.extend_launches++;
         st.shade_launches += s->classes.size();
-        st.connect_launches += s->settings.enable_next_event_estimation ? 1 : 0;
-        const uint64_t eb = EXTEND_BYTES_PER_PATH * n_active;
-        const uint64_t sb = SHADE_BYTES_PER_PATH * shaded + SHADE_BYTES_PER_SURVIVOR * c.n_next + SHADE_BYTES_PER_SHADOW * c.n_shadow;
-        const uint64_t cb = CONNECT_BYTES_PER_SHADOW * c.n_shadow;
+        st.connect_launches += nee ? 1 : 0;
+        const uint64_t eb = EXTEND_BYTES_PER_PATH * n;
+        const uint64_t bb = BIN_BYTES_PER_PATH * n;
+        const uint64_t sb = SHADE_BYTES_PER_PATH * shaded + SHADE_BYTES_PER_SURVIVOR * shaded + SHADE_BYTES_PER_SHADOW * shadows;
+        const uint64_t cb = nee ? CONNECT_BYTES_PER_PATH * shaded + CONNECT_BYTES_PER_SHADOW * shadows : 0;
         st.extend_bytes += eb;
         st.shade_bytes += sb;
         st.connect_bytes += cb;
-        st.algorithmic_bytes += eb + sb + cb;
-        n_active = c.n_next;
+        st.algorithmic_bytes += eb + bb + sb + cb;
+        n = c.total;
         cur ^= 1;
     }
-    unsigned long long shadow_rays = 0;
-    HIP_TRY(hipMemcpyAsync(&shadow_rays, s->d_ray_counter, sizeof(shadow_rays), hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
-    st.shadow_rays += shadow_rays;
+    st.shadow_rays += shadow_before;
     timer.collect();
     return PTK_OK;
 }
@@ -413,7 +408,7 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     if (static_cast<int64_t>(d->settings.width) * d->settings.height > (int64_t(1) << 31))
         return fail(PTK_ERR_INVALID, "ptk_scene_create: image larger than 2^31 pixels");
     if (d->n_objects < 0 || d->n_objects > 65535) return fail(PTK_ERR_INVALID, "ptk_scene_create: at most 65535 top-level objects");
-    if (d->n_media < 1 || d->n_media > 65534) return fail(PTK_ERR_INVALID, "ptk_scene_create: between 1 and 65534 media required");
+    if (d->n_media < 1 || d->n_media > 32766) return fail(PTK_ERR_INVALID, "ptk_scene_create: between 1 and 32766 media required");
     if (d->settings.max_recursion_depth < 0 || d->settings.max_recursion_depth > 8000)
         return fail(PTK_ERR_INVALID, "ptk_scene_create: max_recursion_depth must be in [0, 8000]");
     if (d->background_medium < 0 || d->background_medium >= d->n_media)
@@ -679,9 +674,9 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     HIP_TRY(buf.upload(&dev.nodes, nodes));
     HIP_TRY(buf.upload(&dev.light_cumulative_area, light_area));
     HIP_TRY(buf.upload(&dev.light_tri_index, light_tri));
-    HIP_TRY(buf.alloc(&s->d_counters, 1));
-    HIP_TRY(buf.alloc(&s->d_ray_counter, 1));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), sizeof(BounceCounters), hipHostMallocDefault));
+    HIP_TRY(buf.alloc(&s->d_info, 1));
+    HIP_TRY(buf.alloc(&s->d_ray_counter, 2)); // [0] shadow rays, [1] extension rays
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_info), sizeof(BinInfo), hipHostMallocDefault));
     *out = s.release();
     return PTK_OK;
 }
@@ -689,7 +684,7 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
 void ptk_scene_destroy(PtkScene* scene) {
     if (!scene) return;
     if (g_stream) (void) hipStreamSynchronize(g_stream);
-    if (scene->h_counters) (void) hipHostFree(scene->h_counters);
+    if (scene->h_info) (void) hipHostFree(scene->h_info);
     for (hipEvent_t e : scene->events) (void) hipEventDestroy(e);
     if (scene->host_film) ptk_film_destroy(scene->host_film);
     delete scene;
@@ -738,7 +733,7 @@ int ptk_trace_samples(PtkScene* s, const PtkRenderJob* job, double* color, doubl
     if (position) HIP_TRY(tmp.alloc(&d_pos, total));
     if (normal) HIP_TRY(tmp.alloc(&d_nrm, total));
     rc = for_each_batch(s, job, [&](const BatchParams& b, int64_t pixel_base) {
-        launch_gather_samples(g_stream, b, s->results, static_cast<size_t>(pixel_base), d_color, d_pos, d_nrm);
+        launch_gather_samples(g_stream, b, s->state, static_cast<size_t>(pixel_base), d_color, d_pos, d_nrm);
         HIP_TRY(hipGetLastError());
         return static_cast<int>(PTK_OK);
     });
@@ -848,7 +843,7 @@ int ptk_render(PtkScene* s, PtkFilm* film, const PtkRenderJob* job) {
     if (!film || film->width != s->settings.width || film->height != s->settings.height)
         return fail(PTK_ERR_INVALID, "ptk_render: film size does not match the scene");
     return for_each_batch(s, job, [&](const BatchParams& b, int64_t) {
-        launch_accumulate(g_stream, b, s->results, film->image, film->position, film->normal, film->counters);
+        launch_accumulate(g_stream, b, s->state, film->image, film->position, film->normal, film->counters);
         HIP_TRY(hipGetLastError());
         s->stats.algorithmic_bytes += ACCUMULATE_BYTES_PER_PATH * b.n_paths;
         return static_cast<int>(PTK_OK);
