@@ -137,19 +137,37 @@ def main():
     total_spp = spp * (args.warmup + args.steps)
     offset, _ = sample_slice(rank, world, total_spp * world)
 
-    def step(i):
-        scene.render(film, pt.make_job(0, n_pixels, spp, offset + i * spp, args.seed))
+    # Kernel families are timed with HIP events on the library's stream on every PROFILE_EVERY-th step
+    # of the timed region (event records drain the queue, so timing every step would slow the run).
+    PROFILE_EVERY = 4
+    profiled = {"steps": 0}
+    fam = {k: [0.0, 0, 0] for k in ("k_extend", "k_shade", "k_connect")}
+
+    def step(i, timed=False):
+        job = pt.make_job(0, n_pixels, spp, offset + i * spp, args.seed)
+        if timed and (i - args.warmup) % PROFILE_EVERY == 0:
+            s0 = scene.stats()
+            pt.set_profiling(True)
+            scene.render(film, job)
+            pt.set_profiling(False)
+            s1 = scene.stats()
+            profiled["steps"] += 1
+            for k, f in (("k_extend", "extend"), ("k_shade", "shade"), ("k_connect", "connect")):
+                fam[k][0] += getattr(s1, f + "_ms") - getattr(s0, f + "_ms")
+                fam[k][1] += getattr(s1, f + "_bytes") - getattr(s0, f + "_bytes")
+                fam[k][2] += getattr(s1, f + "_launches") - getattr(s0, f + "_launches")
+        else:
+            scene.render(film, job)
 
     for i in range(args.warmup):
         step(i)
     barrier()
     film.clear()
     scene.reset_stats()
-    pt.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
+        step(args.warmup + i, timed=True)
     pt.sync()
     if distributed:
         import torch
@@ -158,7 +176,6 @@ def main():
         torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    pt.set_profiling(False)
     if distributed:
         import torch
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
@@ -171,11 +188,7 @@ def main():
     value = total_paths / elapsed / 1e6
 
     # dominant kernel family by device time (HIP events on the library's stream, this timed region)
-    families = {
-        "k_extend": (st.extend_ms, st.extend_bytes, st.extend_launches),
-        "k_shade": (st.shade_ms, st.shade_bytes, st.shade_launches),
-        "k_connect": (st.connect_ms, st.connect_bytes, st.connect_launches),
-    }
+    families = {k: tuple(v) for k, v in fam.items()}
     dominant = max(families, key=lambda k: families[k][0])
     d_ms, d_bytes, d_launches = families[dominant]
     achieved = (d_bytes / max(d_launches, 1)) / (d_ms / max(d_launches, 1) * 1e-3) / 1e9 if d_ms > 0 else 0.0
@@ -190,7 +203,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_launch": d_bytes / max(d_launches, 1), "ms_per_launch": d_ms / max(d_launches, 1),
-                "launches": int(d_launches),
+                "launches": int(d_launches), "profiled_steps": profiled["steps"],
                 "device_ms": {k: v[0] for k, v in families.items()}}
 
     out = {

@@ -9,14 +9,16 @@ namespace ptk {
 // number of blocks k_extend / k_bin_scatter use for a list of n entries (= rows of block_counts used)
 uint32_t bin_blocks(uint32_t n);
 
-void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathState& ps, uint32_t* list);
-void launch_extend(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathState& ps, const uint32_t* list, uint32_t n,
-                   uint32_t* block_counts, uint32_t count_stride, unsigned long long* ray_counter);
-// scan + scatter: list_in (n entries) -> class-sorted list_out, summary in *info
-void launch_bin(hipStream_t s, const DevScene& sc, const PathState& ps, const uint32_t* list_in, uint32_t n, uint32_t* block_counts,
-                uint32_t count_stride, BinInfo* info, uint32_t* list_out);
-// `bound` is an upper bound of the number of entries, used only to size the grid; the kernels read
-// the true counts from *info.
+// In every launcher `bound` is an upper bound of the number of list entries, used only to size the
+// grid; the kernels read the true lengths from device memory (*previous: the summary of the list they
+// consume; *info: the summary of the sorted list they produce or walk), so the host never has to wait
+// for a count before it queues the next bounce.
+void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathState& ps, uint32_t* list, BinInfo* first_info);
+void launch_extend(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathState& ps, const uint32_t* list, uint32_t bound,
+                   const BinInfo* previous, uint32_t* block_counts, uint32_t count_stride, unsigned long long* ray_counter);
+// scan + scatter: list_in -> class-sorted list_out, summary in *info
+void launch_bin(hipStream_t s, const DevScene& sc, const PathState& ps, const uint32_t* list_in, uint32_t bound, const BinInfo* previous,
+                uint32_t* block_counts, uint32_t count_stride, BinInfo* info, uint32_t* list_out);
 void launch_shade(hipStream_t s, int cls, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathState& ps,
                   const uint32_t* list, const BinInfo* info);
 void launch_connect(hipStream_t s, uint32_t bound, const DevScene& sc, const PathState& ps, const uint32_t* list, const BinInfo* info,

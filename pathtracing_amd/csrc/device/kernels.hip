@@ -85,7 +85,8 @@ PTK_DEV void camera_ray(const DevScene& sc, uint32_t pixel, Rng& rng, V3& org, V
 }
 
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, PathState st, uint32_t* list) {
+__global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, PathState st, uint32_t* list, BinInfo* first_info) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) first_info->total = b.n_paths; // length of the first list
     for (uint32_t sid = blockIdx.x * BLOCK + threadIdx.x; sid < b.n_paths; sid += gridDim.x * BLOCK) {
         uint32_t pixel, sample;
         sample_coordinates(b, sid, pixel, sample);
@@ -126,8 +127,10 @@ __global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, 
 // Loop head of raytrace (app/pathtracer.cpp:53-67): free-flight distance, closest hit, miss handling.
 // Block b owns list entries [b * BIN_CHUNK, (b + 1) * BIN_CHUNK) and leaves its per-class counts in
 // block_counts[class * count_stride + b].
-__global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, BatchParams b, PathState ps, const uint32_t* list, uint32_t n,
+__global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, BatchParams b, PathState ps, const uint32_t* list, const BinInfo* previous,
                                                   uint32_t* block_counts, uint32_t count_stride, unsigned long long* ray_counter) {
+    const uint32_t n = previous->total; // length of `list`: the sorted list of the previous bounce
+    if (blockIdx.x * BIN_CHUNK >= n) return;
     __shared__ StackEntry lds_stack[LDS_STACK_DEPTH * BLOCK];
     __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
     __shared__ uint32_t wave_rays[BLOCK / 64];
@@ -212,51 +215,77 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, BatchParams b, Pa
 }
 
 // Exclusive scan, in class-major order, of block_counts[class * count_stride + block] for the first
-// n_blocks blocks of every class; one workgroup.  Leaves the offsets in place and the per-class
-// segment starts, counts and the total in `info`.
-__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* block_counts, uint32_t count_stride, uint32_t n_blocks, BinInfo* info) {
-    __shared__ uint32_t partial[1024];
-    __shared__ uint32_t class_start[N_CLASSES + 1];
-    const uint32_t elements = N_CLASSES * n_blocks;
-    const uint32_t per_thread = (elements + 1023) / 1024;
-    const uint32_t first = threadIdx.x * per_thread;
-    const uint32_t last = min(first + per_thread, elements);
-    uint32_t sum = 0;
-    for (uint32_t e = first; e < last; e++) {
-        uint32_t c = e / n_blocks, blk = e - c * n_blocks;
-        sum += block_counts[c * count_stride + blk];
+// n_blocks blocks of every class in class_mask; one workgroup.  Leaves the offsets in place and the
+// per-class segment starts, counts and the total in `info`.  Tiles of 4096 counts: one uint4 per
+// thread, shuffles inside a wave, 16 wave sums through LDS, a running carry across tiles.
+__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* block_counts, uint32_t count_stride, uint32_t class_mask,
+                                                   const BinInfo* previous, BinInfo* info) {
+    const uint32_t n_blocks = (previous->total + BIN_CHUNK - 1) / BIN_CHUNK;
+    __shared__ uint32_t wave_sums[2][16];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0; // the same in every thread
+    int parity = 0;
+    for (int c = 0; c < N_CLASSES; c++) {
+        const uint32_t class_start = carry;
+        if ((class_mask >> c) & 1u) {
+            uint32_t* row = block_counts + static_cast<size_t>(c) * count_stride;
+            for (uint32_t base = 0; base < n_blocks; base += 4096) {
+                const uint32_t i = base + threadIdx.x * 4;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (i + 3 < n_blocks) v = *reinterpret_cast<const uint4*>(row + i);
+                else {
+                    if (i < n_blocks) v.x = row[i];
+                    if (i + 1 < n_blocks) v.y = row[i + 1];
+                    if (i + 2 < n_blocks) v.z = row[i + 2];
+                }
+                const uint32_t mine = v.x + v.y + v.z + v.w;
+                uint32_t incl = mine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    uint32_t up = __shfl_up(incl, off);
+                    if (lane >= static_cast<uint32_t>(off)) incl += up;
+                }
+                if (lane == 63) wave_sums[parity][wave] = incl;
+                __syncthreads();
+                uint32_t before = 0, tile_total = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < 16; w++) {
+                    uint32_t sum = wave_sums[parity][w];
+                    if (w < wave) before += sum;
+                    tile_total += sum;
+                }
+                parity ^= 1; // the other buffer is free: every wave passed the barrier after reading it
+                uint32_t e = carry + before + incl - mine;
+                uint4 o;
+                o.x = e;
+                o.y = e + v.x;
+                o.z = o.y + v.y;
+                o.w = o.z + v.z;
+                if (i + 3 < n_blocks) *reinterpret_cast<uint4*>(row + i) = o;
+                else {
+                    if (i < n_blocks) row[i] = o.x;
+                    if (i + 1 < n_blocks) row[i + 1] = o.y;
+                    if (i + 2 < n_blocks) row[i + 2] = o.z;
+                }
+                carry += tile_total;
+            }
+        }
+        if (threadIdx.x == 0) {
+            info->start[c] = class_start;
+            info->count[c] = carry - class_start;
+        }
     }
-    partial[threadIdx.x] = sum;
-    __syncthreads();
-    // Hillis-Steele inclusive scan of the 1024 partial sums
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint32_t v = threadIdx.x >= off ? partial[threadIdx.x - off] : 0;
-        __syncthreads();
-        partial[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t running = partial[threadIdx.x] - sum; // exclusive prefix of this thread's run
-    for (uint32_t e = first; e < last; e++) {
-        uint32_t c = e / n_blocks, blk = e - c * n_blocks;
-        uint32_t v = block_counts[c * count_stride + blk];
-        block_counts[c * count_stride + blk] = running;
-        if (blk == 0) class_start[c] = running;
-        running += v;
-    }
-    if (threadIdx.x == 1023) class_start[N_CLASSES] = partial[1023];
-    __syncthreads();
-    if (threadIdx.x < N_CLASSES) {
-        info->start[threadIdx.x] = class_start[threadIdx.x];
-        info->count[threadIdx.x] = class_start[threadIdx.x + 1] - class_start[threadIdx.x];
-    }
-    if (threadIdx.x == 0) info->total = class_start[N_CLASSES];
+    if (threadIdx.x == 0) info->total = carry;
 }
 
 // Writes the class-sorted list: entry i of the input list with class c goes to
 // block_offsets[c][block] + (number of class-c entries before it in the block).  Paths that ended
 // (CLASS_DEAD) are dropped.
-__global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathState ps, const uint32_t* list_in, uint32_t n, const uint32_t* block_offsets,
-                                                       uint32_t count_stride, uint32_t class_mask, uint32_t* list_out) {
+__global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathState ps, const uint32_t* list_in, const BinInfo* previous,
+                                                       const uint32_t* block_offsets, uint32_t count_stride, uint32_t class_mask,
+                                                       uint32_t* list_out) {
+    const uint32_t n = previous->total;
+    if (blockIdx.x * BIN_CHUNK >= n) return;
     __shared__ uint32_t counts[BIN_ROUNDS][BLOCK / 64][N_CLASSES];
     const int wave = threadIdx.x >> 6;
     uint32_t slots[BIN_ROUNDS];
@@ -616,22 +645,21 @@ uint32_t bin_blocks(uint32_t n) {
     return n == 0 ? 1u : (n + BIN_CHUNK - 1) / BIN_CHUNK;
 }
 
-void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathState& ps, uint32_t* list) {
-    hipLaunchKernelGGL(k_generate, dim3(grid_for(b.n_paths, 4096)), dim3(BLOCK), 0, s, sc, b, ps, list);
+void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathState& ps, uint32_t* list, BinInfo* first_info) {
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(b.n_paths, 4096)), dim3(BLOCK), 0, s, sc, b, ps, list, first_info);
 }
 
-void launch_extend(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathState& ps, const uint32_t* list, uint32_t n,
-                   uint32_t* block_counts, uint32_t count_stride, unsigned long long* ray_counter) {
-    hipLaunchKernelGGL(k_extend, dim3(bin_blocks(n)), dim3(BLOCK), 0, s, sc, b, ps, list, n, block_counts, count_stride,
+void launch_extend(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathState& ps, const uint32_t* list, uint32_t bound,
+                   const BinInfo* previous, uint32_t* block_counts, uint32_t count_stride, unsigned long long* ray_counter) {
+    hipLaunchKernelGGL(k_extend, dim3(bin_blocks(bound)), dim3(BLOCK), 0, s, sc, b, ps, list, previous, block_counts, count_stride,
                        ray_counter);
 }
 
-void launch_bin(hipStream_t s, const DevScene& sc, const PathState& ps, const uint32_t* list_in, uint32_t n, uint32_t* block_counts,
-                uint32_t count_stride, BinInfo* info, uint32_t* list_out) {
-    const uint32_t blocks = bin_blocks(n);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, block_counts, count_stride, blocks, info);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(blocks), dim3(BLOCK), 0, s, ps, list_in, n, block_counts, count_stride, sc.class_mask,
-                       list_out);
+void launch_bin(hipStream_t s, const DevScene& sc, const PathState& ps, const uint32_t* list_in, uint32_t bound, const BinInfo* previous,
+                uint32_t* block_counts, uint32_t count_stride, BinInfo* info, uint32_t* list_out) {
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, block_counts, count_stride, sc.class_mask, previous, info);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(bin_blocks(bound)), dim3(BLOCK), 0, s, ps, list_in, previous, block_counts, count_stride,
+                       sc.class_mask, list_out);
 }
 
 template<int CLS>

@@ -146,6 +146,7 @@ struct DeviceBuffers {
 };
 
 constexpr int64_t DEFAULT_MAX_PATHS = int64_t(1) << 24;
+constexpr int INFO_RING = 8;
 
 } // namespace
 
@@ -167,8 +168,10 @@ struct PtkScene {
     uint32_t* lists[2] = {nullptr, nullptr}; // ping-pong index lists of live paths
     uint32_t* block_counts = nullptr;        // [N_CLASSES][count_stride]
     uint32_t count_stride = 0;
-    BinInfo* d_info = nullptr;
-    BinInfo* h_info = nullptr; // pinned
+    BinInfo* d_info = nullptr;  // [2]: summaries of the previous and the current bounce's lists
+    BinInfo* h_info = nullptr;  // pinned ring of INFO_RING summaries read back asynchronously
+    hipEvent_t info_events[8] = {};
+    unsigned long long* h_rays = nullptr; // pinned [2]
     unsigned long long* d_ray_counter = nullptr;
     std::vector<int> classes; // queue classes present in the scene
     PtkFilm* host_film = nullptr; // scratch film for ptk_render_host
@@ -198,7 +201,7 @@ int ensure_capacity(PtkScene* s, int64_t paths) {
     HIP_TRY(b.alloc(&p.sh_info, n));
     HIP_TRY(b.alloc(&s->lists[0], n));
     HIP_TRY(b.alloc(&s->lists[1], n));
-    s->count_stride = bin_blocks(static_cast<uint32_t>(n));
+    s->count_stride = (bin_blocks(static_cast<uint32_t>(n)) + 3u) & ~3u; // rows stay 16-byte aligned
     HIP_TRY(b.alloc(&s->block_counts, static_cast<size_t>(s->count_stride) * N_CLASSES));
     s->capacity = paths;
     return PTK_OK;
@@ -259,62 +262,91 @@ struct EventTimer {
 
 // Traces one batch (all samples of a contiguous pixel range) to completion; per-sample results
 // are left in s->state.
+//
+// The host queues bounces without waiting for their counts: kernels read list lengths from device
+// memory, grids are sized by the newest count the host has seen (lengths only shrink), and the
+// per-bounce summaries come back through a ring of pinned slots that is polled, not waited on.
 int trace_batch(PtkScene* s, const BatchParams& b) {
     EventTimer timer{s};
     PtkStats& st = s->stats;
     timer.begin(3);
-    launch_generate(g_stream, s->dev, b, s->state, s->lists[0]);
+    launch_generate(g_stream, s->dev, b, s->state, s->lists[0], &s->d_info[1]);
     timer.end();
     st.paths += b.n_paths;
     st.algorithmic_bytes += GENERATE_BYTES_PER_PATH * b.n_paths;
-    uint32_t n = b.n_paths; // length of the current list (live paths, plus those the last shade ended)
-    int cur = 0;
     const bool nee = s->settings.enable_next_event_estimation != 0;
     HIP_TRY(hipMemsetAsync(s->d_ray_counter, 0, 2 * sizeof(unsigned long long), g_stream));
-    unsigned long long shadow_before = 0, extension_before = 0;
-    for (int depth = 0; depth <= s->settings.max_recursion_depth && n > 0; depth++) {
+
+    uint32_t bound = b.n_paths;   // newest known upper bound of the live-path count
+    uint64_t list_length = b.n_paths; // length of the list the oldest unretired bounce consumed
+    uint64_t sum_lists = 0, sum_shaded = 0;
+    int launched = 0, retired = 0;
+    bool finished = false;
+    auto retire = [&](bool wait) -> int { // consumes completed summaries in order
+        while (retired < launched) {
+            const int slot = retired % INFO_RING;
+            if (wait) HIP_TRY(hipEventSynchronize(s->info_events[slot]));
+            else if (hipEventQuery(s->info_events[slot]) != hipSuccess) break;
+            const uint32_t total = s->h_info[slot].total;
+            sum_lists += list_length;
+            sum_shaded += total;
+            list_length = total;
+            bound = total;
+            if (total == 0) finished = true;
+            retired++;
+        }
+        return PTK_OK;
+    };
+    for (int depth = 0; depth <= s->settings.max_recursion_depth && !finished; depth++) {
+        if (launched - retired == INFO_RING) { // ring full: wait for the oldest summary
+            HIP_TRY(hipEventSynchronize(s->info_events[retired % INFO_RING]));
+        }
+        int rc = retire(false);
+        if (rc != PTK_OK) return rc;
+        if (finished) break;
+        const int cur = depth & 1;
+        BinInfo* previous = &s->d_info[(depth + 1) & 1];
+        BinInfo* info = &s->d_info[depth & 1];
         timer.begin(0);
-        launch_extend(g_stream, s->dev, b, s->state, s->lists[cur], n, s->block_counts, s->count_stride, s->d_ray_counter + 1);
+        launch_extend(g_stream, s->dev, b, s->state, s->lists[cur], bound, previous, s->block_counts, s->count_stride,
+                      s->d_ray_counter + 1);
         timer.end();
         timer.begin(3);
-        launch_bin(g_stream, s->dev, s->state, s->lists[cur], n, s->block_counts, s->count_stride, s->d_info, s->lists[cur ^ 1]);
+        launch_bin(g_stream, s->dev, s->state, s->lists[cur], bound, previous, s->block_counts, s->count_stride, info, s->lists[cur ^ 1]);
         timer.end();
         timer.begin(1);
-        for (int cls : s->classes) launch_shade(g_stream, cls, n, s->dev, b, s->state, s->lists[cur ^ 1], s->d_info);
+        for (int cls : s->classes) launch_shade(g_stream, cls, bound, s->dev, b, s->state, s->lists[cur ^ 1], info);
         timer.end();
         if (nee) {
             timer.begin(2);
-            launch_connect(g_stream, n, s->dev, s->state, s->lists[cur ^ 1], s->d_info, s->d_ray_counter);
+            launch_connect(g_stream, bound, s->dev, s->state, s->lists[cur ^ 1], info, s->d_ray_counter);
             timer.end();
         }
-        HIP_TRY(hipMemcpyAsync(s->h_info, s->d_info, sizeof(BinInfo), hipMemcpyDeviceToHost, g_stream));
-        HIP_TRY(hipMemcpyAsync(&s->h_info->_pad[0], s->d_ray_counter, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, g_stream));
-        HIP_TRY(hipStreamSynchronize(g_stream));
-        const BinInfo& c = *s->h_info;
-        unsigned long long ray_totals[2];
-        std::memcpy(ray_totals, &c._pad[0], sizeof(ray_totals));
-        const uint64_t shadows = ray_totals[0] - shadow_before; // closest-hit queries of this bounce's visibility marches
-        shadow_before = ray_totals[0];
-        st.extension_rays += ray_totals[1] - extension_before;
-        extension_before = ray_totals[1];
-        const uint64_t shaded = c.total;
-        st.vertices += shaded;
+        const int slot = launched % INFO_RING;
+        HIP_TRY(hipMemcpyAsync(&s->h_info[slot], info, sizeof(BinInfo), hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipEventRecord(s->info_events[slot], g_stream));
+        launched++;
         st.bounce_launch_rounds++;
         st.extend_launches++;
         st.shade_launches += s->classes.size();
         st.connect_launches += nee ? 1 : 0;
-        const uint64_t eb = EXTEND_BYTES_PER_PATH * n;
-        const uint64_t bb = BIN_BYTES_PER_PATH * n;
-        const uint64_t sb = SHADE_BYTES_PER_PATH * shaded + SHADE_BYTES_PER_SURVIVOR * shaded + SHADE_BYTES_PER_SHADOW * shadows;
-        const uint64_t cb = nee ? CONNECT_BYTES_PER_PATH * shaded + CONNECT_BYTES_PER_SHADOW * shadows : 0;
-        st.extend_bytes += eb;
-        st.shade_bytes += sb;
-        st.connect_bytes += cb;
-        st.algorithmic_bytes += eb + bb + sb + cb;
-        n = c.total;
-        cur ^= 1;
     }
-    st.shadow_rays += shadow_before;
+    HIP_TRY(hipMemcpyAsync(s->h_rays, s->d_ray_counter, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, g_stream));
+    int rc = retire(true);
+    if (rc != PTK_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    const uint64_t shadows = s->h_rays[0];
+    st.shadow_rays += shadows;
+    st.extension_rays += s->h_rays[1];
+    st.vertices += sum_shaded;
+    const uint64_t eb = EXTEND_BYTES_PER_PATH * sum_lists;
+    const uint64_t bb = BIN_BYTES_PER_PATH * sum_lists;
+    const uint64_t sb = (SHADE_BYTES_PER_PATH + SHADE_BYTES_PER_SURVIVOR) * sum_shaded + SHADE_BYTES_PER_SHADOW * shadows;
+    const uint64_t cb = nee ? CONNECT_BYTES_PER_PATH * sum_shaded + CONNECT_BYTES_PER_SHADOW * shadows : 0;
+    st.extend_bytes += eb;
+    st.shade_bytes += sb;
+    st.connect_bytes += cb;
+    st.algorithmic_bytes += eb + bb + sb + cb;
     timer.collect();
     return PTK_OK;
 }
@@ -674,9 +706,11 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     HIP_TRY(buf.upload(&dev.nodes, nodes));
     HIP_TRY(buf.upload(&dev.light_cumulative_area, light_area));
     HIP_TRY(buf.upload(&dev.light_tri_index, light_tri));
-    HIP_TRY(buf.alloc(&s->d_info, 1));
+    HIP_TRY(buf.alloc(&s->d_info, 2));
     HIP_TRY(buf.alloc(&s->d_ray_counter, 2)); // [0] shadow rays, [1] extension rays
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_info), sizeof(BinInfo), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_info), INFO_RING * sizeof(BinInfo), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_rays), 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    for (int i = 0; i < INFO_RING; i++) HIP_TRY(hipEventCreateWithFlags(&s->info_events[i], hipEventDisableTiming));
     *out = s.release();
     return PTK_OK;
 }
@@ -685,6 +719,9 @@ void ptk_scene_destroy(PtkScene* scene) {
     if (!scene) return;
     if (g_stream) (void) hipStreamSynchronize(g_stream);
     if (scene->h_info) (void) hipHostFree(scene->h_info);
+    if (scene->h_rays) (void) hipHostFree(scene->h_rays);
+    for (hipEvent_t e : scene->info_events)
+        if (e) (void) hipEventDestroy(e);
     for (hipEvent_t e : scene->events) (void) hipEventDestroy(e);
     if (scene->host_film) ptk_film_destroy(scene->host_film);
     delete scene;
