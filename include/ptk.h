@@ -187,9 +187,11 @@ typedef struct PtkStats {
     uint64_t vertices;      /* surface + scatter vertices shaded */
     uint64_t bounce_launch_rounds;
     uint64_t algorithmic_bytes; /* path-state/queue bytes the kernels are specified to move */
-    double extend_ms, shade_ms, connect_ms, other_ms; /* device time per kernel family, HIP events */
-    uint64_t extend_launches, shade_launches, connect_launches;
-    uint64_t extend_bytes, shade_bytes, connect_bytes; /* algorithmic bytes per family */
+    /* Kernel families: trace = visibility marches + extension rays (one fused kernel), shade = the
+     * per-material kernels, bin = the class sort between them. */
+    double trace_ms, shade_ms, bin_ms, other_ms; /* device time per family, HIP events, while profiling is on */
+    uint64_t trace_launches, shade_launches, bin_launches;
+    uint64_t trace_bytes, shade_bytes, bin_bytes; /* algorithmic bytes per family */
 } PtkStats;
 
 /* Selects the GPU for this process (hipSetDevice) and creates the library's stream.

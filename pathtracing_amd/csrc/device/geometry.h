@@ -163,6 +163,8 @@ struct HitInfo {
 
 // find_closest_hit (src/objects.cpp:414-442) without the attribute computation: the linear scan
 // over top-level objects with the shrinking t_max; first object wins exact ties.
+// MESHES = false compiles the BVH traversal (and with it the stack) out, for scenes without meshes.
+template<bool MESHES>
 PTK_DEV bool closest_hit(const DevScene& sc, const V3& org, const V3& dir, double t_max, HitInfo& hit, TraversalStack& st) {
     hit.t = INF;
     hit.obj = -1;
@@ -204,7 +206,7 @@ PTK_DEV bool closest_hit(const DevScene& sc, const V3& org, const V3& dir, doubl
             success = triangle_hit(sc.tri_hot[o.first_tri], org, rp, limit, d);
             prim = static_cast<int>(o.first_tri);
         }
-        else { // mesh
+        else if (MESHES) { // mesh
             double tb = limit;
             int pb = -1;
             mesh_closest_hit(sc, o.bvh_root, o.first_tri, org, dir, rp, tb, pb, st);

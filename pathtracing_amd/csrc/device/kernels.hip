@@ -1,23 +1,26 @@
 // Wavefront path-tracing kernels for gfx950.
 //
-//   k_generate     camera samples -> path state              (compute_pixel_color + Camera::make_ray)
-//   k_extend       free-flight distance + closest hit; records the material class the path hit and
-//                  leaves per-block class counts               (raytrace's loop head + find_closest_hit)
+//   k_generate     camera samples -> path records              (compute_pixel_color + Camera::make_ray)
+//   k_trace        per record: the visibility march of the connection the last shade left pending
+//                  (compute_visibility), then the free-flight distance and the closest hit of the
+//                  new ray (raytrace's loop head + find_closest_hit); records the class of the vertex
+//                  and leaves per-block class counts; paths that ended are flushed to the results
 //   k_bin_scan     exclusive scan of the per-block class counts
-//   k_bin_scatter  writes the class-sorted list of live paths  (stable: list order is preserved)
+//   k_bin_scatter  writes the class-sorted index list           (stable: record order is preserved)
 //   k_shade<C>     one launch per material class over its segment of the list: emission with MIS,
-//                  next-event sampling up to the shadow-ray record, BRDF sampling, medium switch,
-//                  Russian roulette; state is updated in place  (raytrace's loop body)
-//   k_connect      visibility march of the pending shadow rays  (compute_visibility)
+//                  next-event sampling up to the connection record, BRDF sampling, medium switch,
+//                  Russian roulette (raytrace's loop body); reads the record through the list and
+//                  writes the updated record to the other pool at the list position
 //   k_accumulate   per-pixel sample means folded into the film  (compute_pixel_color's division and
 //                  increment_average)
 //
-// One lane owns one path; a path keeps its slot for life and kernels reach the live paths through an
-// index list.  Sorting by class uses block-local ballots and a scan instead of global atomics: with
-// one atomic per wave on a shared counter the kernels ran at the rate of that one cache line
-// (about 100 atomics per microsecond) instead of at the rate of the arithmetic.  All arithmetic is
-// fp64, as in the reference; MFMA has no role here (divergent scalar-per-lane work, no dense
-// contraction).
+// One lane owns one path.  Records move once per bounce, from one pool to the other, which keeps
+// the records in flight packed (coalesced 16-byte accesses whatever fraction of the batch is still
+// alive) at no extra traffic: a shade kernel rewrites most of the record anyway.  Sorting by class
+// uses block-local ballots and a scan instead of global atomics: with one atomic per wave on a
+// shared counter the kernels ran at the rate of that one cache line (about 100 atomics per
+// microsecond) instead of at the rate of the arithmetic.  All arithmetic is fp64, as in the
+// reference; MFMA has no role here (divergent scalar-per-lane work, no dense contraction).
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -84,122 +87,187 @@ PTK_DEV void camera_ray(const DevScene& sc, uint32_t pixel, Rng& rng, V3& org, V
     }
 }
 
+// ---- record access ------------------------------------------------------------------------------
+// A plane's address is uniform (scalar arithmetic); the record index enters as a 32-bit byte offset.
+PTK_DEV char* plane_ptr(const PathPool& p, int plane) {
+    return p.base + static_cast<uint64_t>(plane) * p.plane_bytes;
+}
+PTK_DEV double2 ld2(const PathPool& p, int plane, uint32_t i) {
+    return *reinterpret_cast<const double2*>(plane_ptr(p, plane) + i * 16u);
+}
+PTK_DEV void st2(const PathPool& p, int plane, uint32_t i, double a, double b) {
+    *reinterpret_cast<double2*>(plane_ptr(p, plane) + i * 16u) = make_double2(a, b);
+}
+PTK_DEV uint4 ldu4(const PathPool& p, int plane, uint32_t i) {
+    return *reinterpret_cast<const uint4*>(plane_ptr(p, plane) + i * 16u);
+}
+PTK_DEV void stu4(const PathPool& p, int plane, uint32_t i, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    *reinterpret_cast<uint4*>(plane_ptr(p, plane) + i * 16u) = make_uint4(a, b, c, d);
+}
+PTK_DEV double key_as_double(uint64_t k) { return __longlong_as_double(static_cast<long long>(k)); }
+PTK_DEV uint64_t double_as_key(double d) { return static_cast<uint64_t>(__double_as_longlong(d)); }
+
+// The path ended: its radiance goes to the per-sample results.
+PTK_DEV void flush_color(const SampleResults& res, uint32_t sid, double r, double g, double bl) {
+    double2* c = reinterpret_cast<double2*>(res.color) + 2 * static_cast<size_t>(sid);
+    c[0] = make_double2(r, g);
+    c[1] = make_double2(bl, 0.0);
+}
+PTK_DEV double2* surface_plane(const SampleResults& res, int plane) {
+    return reinterpret_cast<double2*>(res.surface + static_cast<uint64_t>(plane) * res.plane_doubles);
+}
+
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, PathState st, uint32_t* list, BinInfo* first_info) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) first_info->total = b.n_paths; // length of the first list
+__global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, PathPool pool, SampleResults res, BinInfo* first_info) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) first_info->total = b.n_paths; // records in the first pool
     for (uint32_t sid = blockIdx.x * BLOCK + threadIdx.x; sid < b.n_paths; sid += gridDim.x * BLOCK) {
         uint32_t pixel, sample;
         sample_coordinates(b, sid, pixel, sample);
         Rng rng{rng_key(b.seed, pixel, sample), 0};
         V3 org, dir;
         camera_ray(sc, pixel, rng, org, dir);
-        st.ox[sid] = org.x;
-        st.oy[sid] = org.y;
-        st.oz[sid] = org.z;
-        st.dx[sid] = dir.x;
-        st.dy[sid] = dir.y;
-        st.dz[sid] = dir.z;
-        st.tx[sid] = 1.0;
-        st.ty[sid] = 1.0;
-        st.tz[sid] = 1.0;
-        st.sx[sid] = 0.0;
-        st.sy[sid] = 0.0;
-        st.sz[sid] = 0.0;
-        st.spdf[sid] = 0.0;
-        st.ctr[sid] = rng.ctr;
-        st.flags[sid] = 0u | (RAY_TRANSMITTED << TYPE_SHIFT) | (static_cast<uint32_t>(sc.background_medium) << 16);
-        st.cls[sid] = 0;
-        st.sh_info[sid] = 0;
-        st.cr[sid] = 0.0;
-        st.cg[sid] = 0.0;
-        st.cb[sid] = 0.0;
-        st.px[sid] = 0.0;
-        st.py[sid] = 0.0;
-        st.pz[sid] = 0.0;
-        st.nx[sid] = 0.0;
-        st.ny[sid] = 0.0;
-        st.nz[sid] = 0.0;
-        list[sid] = sid;
+        st2(pool, PL_RAY0, sid, org.x, org.y);
+        st2(pool, PL_RAY1, sid, org.z, dir.x);
+        st2(pool, PL_RAY2, sid, dir.y, dir.z);
+        st2(pool, PL_THR0, sid, 1.0, 1.0);
+        st2(pool, PL_THR1, sid, 1.0, 0.0);
+        st2(pool, PL_SAV0, sid, 0.0, 0.0);
+        st2(pool, PL_SAV1, sid, 0.0, 0.0);
+        st2(pool, PL_COL0, sid, 0.0, 0.0);
+        st2(pool, PL_COL1, sid, 0.0, 0.0);
+        stu4(pool, PL_IDS, sid, 0u | (RAY_TRANSMITTED << TYPE_SHIFT) | (static_cast<uint32_t>(sc.background_medium) << 16), sid,
+             rng.ctr, 0u);
+        pool.cls[sid] = 0;
+        surface_plane(res, 0)[sid] = make_double2(0.0, 0.0);
+        surface_plane(res, 1)[sid] = make_double2(0.0, 0.0);
+        surface_plane(res, 2)[sid] = make_double2(0.0, 0.0);
     }
 }
 
 // -------------------------------------------------------------------------------------------------
-// Loop head of raytrace (app/pathtracer.cpp:53-67): free-flight distance, closest hit, miss handling.
-// Block b owns list entries [b * BIN_CHUNK, (b + 1) * BIN_CHUNK) and leaves its per-class counts in
-// block_counts[class * count_stride + b].
-__global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, BatchParams b, PathState ps, const uint32_t* list, const BinInfo* previous,
-                                                  uint32_t* block_counts, uint32_t count_stride, unsigned long long* ray_counter) {
-    const uint32_t n = previous->total; // length of `list`: the sorted list of the previous bounce
+// For every record of the current pool: finish the connection the last shade left pending
+// (compute_visibility, src/objects.cpp:470-513, and the acceptance test of sample_light :558), then
+// run the loop head of raytrace (app/pathtracer.cpp:53-67) for the new ray: free-flight distance,
+// closest hit, miss handling.  Block b owns records [b * BIN_CHUNK, (b + 1) * BIN_CHUNK) and leaves
+// its per-class counts in block_counts[class * count_stride + b].
+// counters: [0] visibility-march segments, [1] extension rays, [2] connections marched.
+template<bool MESHES>
+__global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, BatchParams b, PathPool pool, SampleResults res, const BinInfo* previous,
+                                                 uint32_t* block_counts, uint32_t count_stride, unsigned long long* counters) {
+    const uint32_t n = previous->total; // records the previous bounce's shade kernels wrote
     if (blockIdx.x * BIN_CHUNK >= n) return;
-    __shared__ StackEntry lds_stack[LDS_STACK_DEPTH * BLOCK];
+    __shared__ StackEntry lds_stack[MESHES ? LDS_STACK_DEPTH * BLOCK : 1];
     __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
-    __shared__ uint32_t wave_rays[BLOCK / 64];
-    uint32_t my_rays = 0;
+    __shared__ uint32_t wave_rays[BLOCK / 64][3];
     TraversalStack st = make_stack(lds_stack);
     uint32_t my_counts[N_CLASSES];
-    uint32_t wave_rays_acc = 0;
 #pragma unroll
     for (int c = 0; c < N_CLASSES; c++) my_counts[c] = 0;
+    uint32_t segments = 0, extensions = 0, connections = 0; // per lane
     for (int r = 0; r < BIN_ROUNDS; r++) {
         const uint32_t idx = blockIdx.x * BIN_CHUNK + r * BLOCK + threadIdx.x;
         int cls = -1;
-        if (idx < n) {
-            const uint32_t slot = list[idx];
-            if (ps.cls[slot] != CLASS_DEAD) {
-                V3 org = v3(ps.ox[slot], ps.oy[slot], ps.oz[slot]);
-                V3 dir = v3(ps.dx[slot], ps.dy[slot], ps.dz[slot]);
-                const uint32_t flags = ps.flags[slot];
-                uint32_t medium = flags >> 16;
+        const uint8_t mark = idx < n ? pool.cls[idx] : CLASS_DONE;
+        if (mark != CLASS_DONE) {
+            const uint4 ids = ldu4(pool, PL_IDS, idx);
+            const double2 r0 = ld2(pool, PL_RAY0, idx), r1 = ld2(pool, PL_RAY1, idx);
+            const V3 org = v3(r0.x, r0.y, r1.x);
+            const uint32_t sid = ids.y;
+            double2 c0 = make_double2(0.0, 0.0), c1 = c0;
+            bool color_loaded = false, color_changed = false;
+            if (ids.w & SHADOW_VALID) {
+                c0 = ld2(pool, PL_COL0, idx);
+                c1 = ld2(pool, PL_COL1, idx);
+                color_loaded = true;
+                const double2 s0 = ld2(pool, PL_SH0, idx), s1 = ld2(pool, PL_SH1, idx), s2 = ld2(pool, PL_SH2, idx);
+                const double2 v1 = ld2(pool, PL_SAV1, idx);
+                Rng rng{double_as_key(c1.y), 0};
+                connections++;
+                V3 visible = march_to_light<MESHES>(sc, org, v3(s0.x, s0.y, s1.x), static_cast<int>((ids.w >> 16) & 0x7FFFu),
+                                                    static_cast<int>(ids.w & 0xFFFFu), s1.y, rng, st, segments);
+                if (visible.x != 0 || visible.y != 0 || visible.z != 0) {
+                    c0.x += s2.x * visible.x;
+                    c0.y += s2.y * visible.y;
+                    c1.x += v1.y * visible.z;
+                    color_changed = true;
+                }
+            }
+            if (mark == CLASS_DEAD) {
+                if (!color_loaded) {
+                    c0 = ld2(pool, PL_COL0, idx);
+                    c1 = ld2(pool, PL_COL1, idx);
+                }
+                flush_color(res, sid, c0.x, c0.y, c1.x);
+            }
+            else {
+                const double2 r2 = ld2(pool, PL_RAY2, idx);
+                const V3 dir = v3(r1.y, r2.x, r2.y);
+                uint32_t medium = ids.x >> 16;
                 if (medium == MEDIUM_NONE) medium = static_cast<uint32_t>(sc.background_medium);
                 const DevMedium& med = sc.media[medium];
                 double scatter_distance = INF;
                 if (med.type == PTK_MEDIUM_HOMOGENEOUS_SCATTERING) { // HomogenousScatteringMedium::sample_distance
                     uint32_t pixel, sample;
-                    sample_coordinates(b, slot, pixel, sample);
-                    Rng rng{rng_key(b.seed, pixel, sample), ps.ctr[slot]};
+                    sample_coordinates(b, sid, pixel, sample);
+                    Rng rng{rng_key(b.seed, pixel, sample), ids.z};
                     int channel = rng.integer(0, 3);
                     double ext = med.extinction[channel];
                     if (ext != 0) scatter_distance = -log(rng.u01()) / ext;
                 }
                 HitInfo h;
-                bool found = closest_hit(sc, org, dir, scatter_distance, h, st);
-                my_rays = 1;
+                bool found = closest_hit<MESHES>(sc, org, dir, scatter_distance, h, st);
+                extensions++;
                 if (!found && scatter_distance == INF) {
                     // color += throughput * background_color; the path ends
-                    if (!sc.background_is_black) {
-                        ps.cr[slot] += ps.tx[slot] * sc.background[0];
-                        ps.cg[slot] += ps.ty[slot] * sc.background[1];
-                        ps.cb[slot] += ps.tz[slot] * sc.background[2];
+                    if (!color_loaded) {
+                        c0 = ld2(pool, PL_COL0, idx);
+                        c1 = ld2(pool, PL_COL1, idx);
                     }
-                    ps.cls[slot] = CLASS_DEAD;
-                }
-                else if (!found) { // scatter event before any surface
-                    ps.hit_t[slot] = scatter_distance;
-                    ps.hit_obj[slot] = -1;
-                    ps.hit_prim[slot] = 0;
-                    cls = CLASS_SCATTER;
-                    ps.cls[slot] = CLASS_SCATTER;
+                    if (!sc.background_is_black) {
+                        const double2 t0 = ld2(pool, PL_THR0, idx), t1 = ld2(pool, PL_THR1, idx);
+                        c0.x += t0.x * sc.background[0];
+                        c0.y += t0.y * sc.background[1];
+                        c1.x += t1.x * sc.background[2];
+                    }
+                    flush_color(res, sid, c0.x, c0.y, c1.x);
+                    pool.cls[idx] = CLASS_DONE;
                 }
                 else {
-                    ps.hit_t[slot] = h.t;
-                    ps.hit_obj[slot] = h.obj;
-                    ps.hit_prim[slot] = h.prim;
-                    cls = sc.materials[sc.objects[h.obj].material].type;
-                    ps.cls[slot] = static_cast<uint8_t>(cls);
+                    int obj = -1, prim = 0;
+                    double t = scatter_distance;
+                    cls = CLASS_SCATTER; // scatter event before any surface
+                    if (found) {
+                        t = h.t;
+                        obj = h.obj;
+                        prim = h.prim;
+                        cls = sc.materials[sc.objects[h.obj].material].type;
+                    }
+                    stu4(pool, PL_HIT, idx, static_cast<uint32_t>(__double2loint(t)), static_cast<uint32_t>(__double2hiint(t)),
+                         static_cast<uint32_t>(obj), static_cast<uint32_t>(prim));
+                    pool.cls[idx] = static_cast<uint8_t>(cls);
+                    if (color_changed) {
+                        st2(pool, PL_COL0, idx, c0.x, c0.y);
+                        st2(pool, PL_COL1, idx, c1.x, c1.y);
+                    }
                 }
             }
         }
 #pragma unroll
         for (int c = 0; c < N_CLASSES; c++)
             if ((sc.class_mask >> c) & 1u) my_counts[c] += static_cast<uint32_t>(__popcll(__ballot(cls == c)));
-        wave_rays_acc += static_cast<uint32_t>(__popcll(__ballot(my_rays != 0)));
-        my_rays = 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        segments += __shfl_down(segments, off);
+        extensions += __shfl_down(extensions, off);
+        connections += __shfl_down(connections, off);
     }
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int c = 0; c < N_CLASSES; c++) wave_counts[wave][c] = my_counts[c];
-        wave_rays[wave] = wave_rays_acc;
+        wave_rays[wave][0] = segments;
+        wave_rays[wave][1] = extensions;
+        wave_rays[wave][2] = connections;
     }
     __syncthreads();
     if (threadIdx.x < N_CLASSES) {
@@ -207,10 +275,11 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, BatchParams b, Pa
         for (int w = 0; w < BLOCK / 64; w++) total += wave_counts[w][threadIdx.x];
         block_counts[threadIdx.x * count_stride + blockIdx.x] = total;
     }
-    if (threadIdx.x == 0) { // rays traced, for the statistics: one atomic per block
+    if (threadIdx.x >= 64 && threadIdx.x < 67) { // statistics: one atomic per block and counter
+        const int k = threadIdx.x - 64;
         uint32_t total = 0;
-        for (int w = 0; w < BLOCK / 64; w++) total += wave_rays[w];
-        if (total) atomicAdd(ray_counter, static_cast<unsigned long long>(total));
+        for (int w = 0; w < BLOCK / 64; w++) total += wave_rays[w][k];
+        if (total) atomicAdd(counters + k, static_cast<unsigned long long>(total));
     }
 }
 
@@ -278,30 +347,24 @@ __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* block_counts, uint3
     if (threadIdx.x == 0) info->total = carry;
 }
 
-// Writes the class-sorted list: entry i of the input list with class c goes to
-// block_offsets[c][block] + (number of class-c entries before it in the block).  Paths that ended
-// (CLASS_DEAD) are dropped.
-__global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathState ps, const uint32_t* list_in, const BinInfo* previous,
-                                                       const uint32_t* block_offsets, uint32_t count_stride, uint32_t class_mask,
-                                                       uint32_t* list_out) {
+// Writes the class-sorted index list: record i of class c goes to block_offsets[c][block] + (number
+// of class-c records before it in the block).  Records of paths that ended are left out.
+__global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathPool pool, const BinInfo* previous, const uint32_t* block_offsets,
+                                                       uint32_t count_stride, uint32_t class_mask, uint32_t* list_out) {
     const uint32_t n = previous->total;
     if (blockIdx.x * BIN_CHUNK >= n) return;
     __shared__ uint32_t counts[BIN_ROUNDS][BLOCK / 64][N_CLASSES];
     const int wave = threadIdx.x >> 6;
-    uint32_t slots[BIN_ROUNDS];
     int classes[BIN_ROUNDS];
     uint32_t below[BIN_ROUNDS];
 #pragma unroll
     for (int r = 0; r < BIN_ROUNDS; r++) {
         const uint32_t idx = blockIdx.x * BIN_CHUNK + r * BLOCK + threadIdx.x;
         int cls = -1;
-        uint32_t slot = 0;
         if (idx < n) {
-            slot = list_in[idx];
-            const uint8_t c = ps.cls[slot];
-            if (c != CLASS_DEAD) cls = c;
+            const uint8_t c = pool.cls[idx];
+            if (c < N_CLASSES) cls = c;
         }
-        slots[r] = slot;
         classes[r] = cls;
         below[r] = 0;
 #pragma unroll
@@ -326,23 +389,35 @@ __global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathState ps, const uint3
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < BIN_ROUNDS; r++)
-        if (classes[r] >= 0) list_out[counts[r][wave][classes[r]] + below[r]] = slots[r];
+        if (classes[r] >= 0) list_out[counts[r][wave][classes[r]] + below[r]] = blockIdx.x * BIN_CHUNK + r * BLOCK + threadIdx.x;
 }
 
 // -------------------------------------------------------------------------------------------------
-// Loop body of raytrace (app/pathtracer.cpp:69-171) for the paths of one class.
+// Loop body of raytrace (app/pathtracer.cpp:69-171) for the vertices of one class.  Reads record
+// list[first + j] of `in`, writes record first + j of `out`.
+// counters[3]: records that needed nothing further (path ended, no connection pending).
 template<int CLS>
-__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, BatchParams b, PathState ps, const uint32_t* list, const BinInfo* info) {
+__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, BatchParams b, PathPool in, PathPool out, SampleResults res,
+                                                 const uint32_t* list, const BinInfo* info, unsigned long long* counters) {
     const uint32_t n = info->count[CLS];
     const uint32_t first = info->start[CLS];
+    uint32_t finished = 0;
     for (uint32_t qi = blockIdx.x * BLOCK + threadIdx.x; qi < n; qi += gridDim.x * BLOCK) {
-        const uint32_t slot = list[first + qi];
-        V3 org = v3(ps.ox[slot], ps.oy[slot], ps.oz[slot]);
-        V3 dir = v3(ps.dx[slot], ps.dy[slot], ps.dz[slot]);
-        V3 thr = v3(ps.tx[slot], ps.ty[slot], ps.tz[slot]);
-        V3 saved = v3(ps.sx[slot], ps.sy[slot], ps.sz[slot]);
-        double scatter_pdf = ps.spdf[slot];
-        const uint32_t flags = ps.flags[slot];
+        const uint32_t dst = first + qi;
+        const uint32_t src = list[dst];
+        const double2 r0 = ld2(in, PL_RAY0, src), r1 = ld2(in, PL_RAY1, src), r2 = ld2(in, PL_RAY2, src);
+        const double2 t0 = ld2(in, PL_THR0, src), t1 = ld2(in, PL_THR1, src);
+        const double2 v0 = ld2(in, PL_SAV0, src), v1 = ld2(in, PL_SAV1, src);
+        double2 c0 = ld2(in, PL_COL0, src), c1 = ld2(in, PL_COL1, src);
+        const uint4 ids = ldu4(in, PL_IDS, src);
+        const uint4 hit = ldu4(in, PL_HIT, src);
+        V3 org = v3(r0.x, r0.y, r1.x);
+        V3 dir = v3(r1.y, r2.x, r2.y);
+        V3 thr = v3(t0.x, t0.y, t1.x);
+        V3 saved = v3(v0.x, v0.y, v1.x);
+        double scatter_pdf = t1.y;
+        const uint32_t flags = ids.x;
+        const uint32_t sid = ids.y;
         const uint32_t depth = flags & DEPTH_MASK;
         uint32_t ray_type = (flags >> TYPE_SHIFT) & 3u;
         bool has_hit = (flags & FLAG_HAS_HIT) != 0;
@@ -350,43 +425,39 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, BatchParams b, Pat
         if (medium == MEDIUM_NONE) medium = static_cast<uint32_t>(sc.background_medium);
         const DevMedium& med = sc.media[medium];
         uint32_t pixel, sample;
-        sample_coordinates(b, slot, pixel, sample);
-        Rng rng{rng_key(b.seed, pixel, sample), ps.ctr[slot]};
+        sample_coordinates(b, sid, pixel, sample);
+        Rng rng{rng_key(b.seed, pixel, sample), ids.z};
         if (med.type == PTK_MEDIUM_HOMOGENEOUS_SCATTERING) {
-            // the numbers k_extend drew for the free-flight distance: the channel, and the
+            // the numbers k_trace drew for the free-flight distance: the channel, and the
             // distance only when that channel attenuates (src/medium.cpp:45-51)
             int channel = rng.integer(0, 3);
             if (med.extinction[channel] != 0) rng.ctr++;
         }
-        const double t = ps.hit_t[slot];
+        const double t = __hiloint2double(static_cast<int>(hit.y), static_cast<int>(hit.x));
         const V3 point = org + dir * t;
         int next_medium = static_cast<int>(medium);
         V3 n_dir;
         uint32_t sh_info = 0;
+        V3 sh_dir = v3(0.0), sh_contrib = v3(0.0);
+        double sh_dist = 0;
+        uint64_t sh_key = 0;
 
         if (CLS == CLASS_SCATTER) {
             // :71-93
             V3 emission = medium_emission(med) * thr;
-            if (emission.x != 0 || emission.y != 0 || emission.z != 0) {
-                ps.cr[slot] += emission.x;
-                ps.cg[slot] += emission.y;
-                ps.cb[slot] += emission.z;
-            }
+            c0.x += emission.x;
+            c0.y += emission.y;
+            c1.x += emission.z;
             thr = thr * medium_sample_weight(med, t, true);
             n_dir = sample_spherical(rng);
             if (sc.nee) {
                 LightSample ls;
                 if (pick_light_point(sc, -1, point, ls, rng)) {
                     double weight = mis_weight(ls.light_pdf, PHASE_ISOTROPIC);
-                    V3 contrib = thr * (weight * PHASE_ISOTROPIC / ls.light_pdf * static_cast<double>(sc.n_lights));
-                    ps.sh_dx[slot] = ls.direction.x;
-                    ps.sh_dy[slot] = ls.direction.y;
-                    ps.sh_dz[slot] = ls.direction.z;
-                    ps.sh_dist[slot] = ls.distance;
-                    ps.sh_cr[slot] = contrib.x;
-                    ps.sh_cg[slot] = contrib.y;
-                    ps.sh_cb[slot] = contrib.z;
-                    ps.sh_key[slot] = rng_fork(rng.key, rng.ctr);
+                    sh_contrib = thr * (weight * PHASE_ISOTROPIC / ls.light_pdf * static_cast<double>(sc.n_lights));
+                    sh_dir = ls.direction;
+                    sh_dist = ls.distance;
+                    sh_key = rng_fork(rng.key, rng.ctr);
                     rng.ctr++;
                     sh_info = SHADOW_VALID | static_cast<uint32_t>(ls.light_index) | (medium << 16);
                 }
@@ -398,8 +469,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, BatchParams b, Pat
         else {
             // :94-155
             thr = thr * medium_sample_weight(med, t, false);
-            const int obj = ps.hit_obj[slot];
-            const int prim = ps.hit_prim[slot];
+            const int obj = static_cast<int>(hit.z);
+            const int prim = static_cast<int>(hit.w);
             const DevObject& o = sc.objects[obj];
             const DevMaterial& m = sc.materials[o.material];
             Surface s;
@@ -415,12 +486,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, BatchParams b, Pat
             if (s.use_uv) object_uv(sc, o, point, prim, s.u, s.v);
 
             if (!has_hit) {
-                ps.px[slot] = point.x;
-                ps.py[slot] = point.y;
-                ps.pz[slot] = point.z;
-                ps.nx[slot] = s.normal.x;
-                ps.ny[slot] = s.normal.y;
-                ps.nz[slot] = s.normal.z;
+                surface_plane(res, 0)[sid] = make_double2(point.x, point.y);
+                surface_plane(res, 1)[sid] = make_double2(point.z, s.normal.x);
+                surface_plane(res, 2)[sid] = make_double2(s.normal.y, s.normal.z);
                 has_hit = true;
             }
             const bool is_specular = ray_type == RAY_REFLECTED || ray_type == RAY_TRANSMITTED;
@@ -429,9 +497,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, BatchParams b, Pat
                 if (sc.nee && depth != 0 && !is_specular)
                     weight = mis_weight(scatter_pdf, object_light_pdf(sc, o, point, saved, prim));
                 V3 add = material_emittance(sc, m, s.use_uv, s.u, s.v) * weight * thr;
-                ps.cr[slot] += add.x;
-                ps.cg[slot] += add.y;
-                ps.cb[slot] += add.z;
+                c0.x += add.x;
+                c0.y += add.y;
+                c1.x += add.z;
             }
             if (sc.nee) { // sample_light up to the march (src/objects.cpp:515-551, 562-578)
                 LightSample ls;
@@ -445,15 +513,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, BatchParams b, Pat
                         double cosine = fmax(dot(s.normal, ls.direction), 0.0);
                         if (!wrong_side && cosine > 0) {
                             double weight = mis_weight(ls.light_pdf, pdf);
-                            V3 contrib = brdf * thr * (weight * cosine / ls.light_pdf * static_cast<double>(sc.n_lights));
-                            ps.sh_dx[slot] = ls.direction.x;
-                            ps.sh_dy[slot] = ls.direction.y;
-                            ps.sh_dz[slot] = ls.direction.z;
-                            ps.sh_dist[slot] = ls.distance;
-                            ps.sh_cr[slot] = contrib.x;
-                            ps.sh_cg[slot] = contrib.y;
-                            ps.sh_cb[slot] = contrib.z;
-                            ps.sh_key[slot] = key;
+                            sh_contrib = brdf * thr * (weight * cosine / ls.light_pdf * static_cast<double>(sc.n_lights));
+                            sh_dir = ls.direction;
+                            sh_dist = ls.distance;
+                            sh_key = key;
                             sh_info = SHADOW_VALID | static_cast<uint32_t>(ls.light_index) | (medium << 16);
                         }
                     }
@@ -484,83 +547,61 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, BatchParams b, Pat
         }
         const bool alive = allow && static_cast<int>(depth) + 1 <= sc.max_depth;
 
-        ps.sh_info[slot] = sh_info;
-        ps.ox[slot] = point.x; // the new ray's origin, and the origin of the pending shadow ray
-        ps.oy[slot] = point.y;
-        ps.oz[slot] = point.z;
+        if (!alive && !(sh_info & SHADOW_VALID)) { // nothing left to do for this path
+            flush_color(res, sid, c0.x, c0.y, c1.x);
+            out.cls[dst] = CLASS_DONE;
+            finished++;
+            continue;
+        }
+        // the new ray's origin is also the origin of the pending connection
+        st2(out, PL_RAY0, dst, point.x, point.y);
+        st2(out, PL_RAY1, dst, point.z, n_dir.x);
+        st2(out, PL_SAV1, dst, saved.z, sh_contrib.z);
+        st2(out, PL_COL0, dst, c0.x, c0.y);
+        st2(out, PL_COL1, dst, c1.x, key_as_double(sh_key));
+        stu4(out, PL_IDS, dst,
+             (depth + 1) | (ray_type << TYPE_SHIFT) | (has_hit ? FLAG_HAS_HIT : 0u) |
+                 ((next_medium < 0 ? MEDIUM_NONE : static_cast<uint32_t>(next_medium)) << 16),
+             sid, rng.ctr, sh_info);
+        if (sh_info & SHADOW_VALID) {
+            st2(out, PL_SH0, dst, sh_dir.x, sh_dir.y);
+            st2(out, PL_SH1, dst, sh_dir.z, sh_dist);
+            st2(out, PL_SH2, dst, sh_contrib.x, sh_contrib.y);
+        }
         if (alive) {
-            ps.dx[slot] = n_dir.x;
-            ps.dy[slot] = n_dir.y;
-            ps.dz[slot] = n_dir.z;
-            ps.tx[slot] = thr.x;
-            ps.ty[slot] = thr.y;
-            ps.tz[slot] = thr.z;
-            ps.sx[slot] = saved.x;
-            ps.sy[slot] = saved.y;
-            ps.sz[slot] = saved.z;
-            ps.spdf[slot] = scatter_pdf;
-            ps.ctr[slot] = rng.ctr;
-            ps.flags[slot] = (depth + 1) | (ray_type << TYPE_SHIFT) | (has_hit ? FLAG_HAS_HIT : 0u) |
-                             ((next_medium < 0 ? MEDIUM_NONE : static_cast<uint32_t>(next_medium)) << 16);
+            st2(out, PL_RAY2, dst, n_dir.y, n_dir.z);
+            st2(out, PL_THR0, dst, thr.x, thr.y);
+            st2(out, PL_THR1, dst, thr.z, scatter_pdf);
+            st2(out, PL_SAV0, dst, saved.x, saved.y);
         }
-        else {
-            ps.cls[slot] = CLASS_DEAD;
-        }
+        out.cls[dst] = alive ? 0 : CLASS_DEAD;
     }
-}
-
-// -------------------------------------------------------------------------------------------------
-// Visibility march for every path of the bounce's list that has a pending connection.
-__global__ __launch_bounds__(BLOCK) void k_connect(DevScene sc, PathState ps, const uint32_t* list, const BinInfo* info,
-                                                   unsigned long long* ray_counter) {
-    __shared__ StackEntry lds_stack[LDS_STACK_DEPTH * BLOCK];
-    __shared__ uint32_t block_rays;
-    TraversalStack st = make_stack(lds_stack);
-    if (threadIdx.x == 0) block_rays = 0;
-    __syncthreads();
-    const uint32_t n = info->total;
-    uint32_t rays = 0;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
-        const uint32_t slot = list[i];
-        const uint32_t sh = ps.sh_info[slot];
-        if (!(sh & SHADOW_VALID)) continue;
-        V3 org = v3(ps.ox[slot], ps.oy[slot], ps.oz[slot]);
-        V3 dir = v3(ps.sh_dx[slot], ps.sh_dy[slot], ps.sh_dz[slot]);
-        uint32_t medium = (sh >> 16) & 0x7FFFu;
-        Rng rng{ps.sh_key[slot], 0};
-        V3 visible = march_to_light(sc, org, dir, static_cast<int>(medium), static_cast<int>(sh & 0xFFFFu), ps.sh_dist[slot], rng,
-                                    st, rays);
-        if (visible.x != 0 || visible.y != 0 || visible.z != 0) {
-            ps.cr[slot] += ps.sh_cr[slot] * visible.x;
-            ps.cg[slot] += ps.sh_cg[slot] * visible.y;
-            ps.cb[slot] += ps.sh_cb[slot] * visible.z;
-        }
-    }
-    // shadow-ray count for the statistics: one global atomic per block
-    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
-    if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&block_rays, rays);
-    __syncthreads();
-    if (threadIdx.x == 0 && block_rays) atomicAdd(ray_counter, static_cast<unsigned long long>(block_rays));
+    // statistics: one atomic per wave that finished anything (rare: most ended paths still connect)
+    for (int off = 32; off > 0; off >>= 1) finished += __shfl_down(finished, off);
+    if ((threadIdx.x & 63) == 0 && finished) atomicAdd(counters + 3, static_cast<unsigned long long>(finished));
 }
 
 // -------------------------------------------------------------------------------------------------
 // compute_pixel_color's mean over the batch's samples (app/pathtracer.cpp:192-199) and
 // raytrace_section's running mean (:232-235, 253-267); one lane per pixel, samples in order.
-__global__ __launch_bounds__(BLOCK) void k_accumulate(BatchParams b, PathState res, double* image, double* position,
+__global__ __launch_bounds__(BLOCK) void k_accumulate(BatchParams b, SampleResults res, double* image, double* position,
                                                       double* normal, unsigned long long* pixel_counters) {
     for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < b.n_pixels; p += gridDim.x * BLOCK) {
         double sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (uint32_t s = 0; s < b.n_samples; s++) {
             const size_t sid = static_cast<size_t>(s) * b.n_pixels + p;
-            sum[0] += res.cr[sid];
-            sum[1] += res.cg[sid];
-            sum[2] += res.cb[sid];
-            sum[3] += res.px[sid];
-            sum[4] += res.py[sid];
-            sum[5] += res.pz[sid];
-            sum[6] += res.nx[sid];
-            sum[7] += res.ny[sid];
-            sum[8] += res.nz[sid];
+            const double2* c = reinterpret_cast<const double2*>(res.color) + 2 * sid;
+            const double2 ca = c[0], cb = c[1];
+            const double2 s0 = surface_plane(res, 0)[sid], s1 = surface_plane(res, 1)[sid], s2 = surface_plane(res, 2)[sid];
+            sum[0] += ca.x;
+            sum[1] += ca.y;
+            sum[2] += cb.x;
+            sum[3] += s0.x;
+            sum[4] += s0.y;
+            sum[5] += s1.x;
+            sum[6] += s1.y;
+            sum[7] += s2.x;
+            sum[8] += s2.y;
         }
         const double n_add = static_cast<double>(b.n_samples);
         const size_t idx = static_cast<size_t>(b.start_idx) + p;
@@ -575,25 +616,28 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(BatchParams b, PathState r
 }
 
 // Copies per-sample results to [pixel][sample][3] host-order arrays (ptk_trace_samples).
-__global__ __launch_bounds__(BLOCK) void k_gather_samples(BatchParams b, PathState res, size_t pixel_base,
+__global__ __launch_bounds__(BLOCK) void k_gather_samples(BatchParams b, SampleResults res, size_t pixel_base,
                                                           double* color, double* position, double* normal) {
     for (uint32_t sid = blockIdx.x * BLOCK + threadIdx.x; sid < b.n_paths; sid += gridDim.x * BLOCK) {
         uint32_t s = sid / b.n_pixels, p = sid - s * b.n_pixels;
         size_t o = 3 * ((pixel_base + p) * b.n_samples + s);
         if (color) {
-            color[o] = res.cr[sid];
-            color[o + 1] = res.cg[sid];
-            color[o + 2] = res.cb[sid];
+            const double2* c = reinterpret_cast<const double2*>(res.color) + 2 * static_cast<size_t>(sid);
+            const double2 ca = c[0], cb = c[1];
+            color[o] = ca.x;
+            color[o + 1] = ca.y;
+            color[o + 2] = cb.x;
         }
+        const double2 s0 = surface_plane(res, 0)[sid], s1 = surface_plane(res, 1)[sid], s2 = surface_plane(res, 2)[sid];
         if (position) {
-            position[o] = res.px[sid];
-            position[o + 1] = res.py[sid];
-            position[o + 2] = res.pz[sid];
+            position[o] = s0.x;
+            position[o + 1] = s0.y;
+            position[o + 2] = s1.x;
         }
         if (normal) {
-            normal[o] = res.nx[sid];
-            normal[o + 1] = res.ny[sid];
-            normal[o + 2] = res.nz[sid];
+            normal[o] = s1.y;
+            normal[o + 1] = s2.x;
+            normal[o + 2] = s2.y;
         }
     }
 }
@@ -610,7 +654,7 @@ __global__ __launch_bounds__(BLOCK) void k_primary(DevScene sc, BatchParams b, i
         V3 org, dir;
         camera_ray(sc, pixel, rng, org, dir);
         HitInfo h;
-        bool found = closest_hit(sc, org, dir, INF, h, st);
+        bool found = closest_hit<true>(sc, org, dir, INF, h, st);
         V3 point = v3(0.0), n = v3(0.0);
         int prim = 0;
         if (found) {
@@ -645,58 +689,60 @@ uint32_t bin_blocks(uint32_t n) {
     return n == 0 ? 1u : (n + BIN_CHUNK - 1) / BIN_CHUNK;
 }
 
-void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathState& ps, uint32_t* list, BinInfo* first_info) {
-    hipLaunchKernelGGL(k_generate, dim3(grid_for(b.n_paths, 4096)), dim3(BLOCK), 0, s, sc, b, ps, list, first_info);
+void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathPool& pool, const SampleResults& res,
+                     BinInfo* first_info) {
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(b.n_paths, 4096)), dim3(BLOCK), 0, s, sc, b, pool, res, first_info);
 }
 
-void launch_extend(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathState& ps, const uint32_t* list, uint32_t bound,
-                   const BinInfo* previous, uint32_t* block_counts, uint32_t count_stride, unsigned long long* ray_counter) {
-    hipLaunchKernelGGL(k_extend, dim3(bin_blocks(bound)), dim3(BLOCK), 0, s, sc, b, ps, list, previous, block_counts, count_stride,
-                       ray_counter);
+void launch_trace(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathPool& pool, const SampleResults& res, uint32_t bound,
+                  const BinInfo* previous, uint32_t* block_counts, uint32_t count_stride, unsigned long long* counters) {
+    if (sc.has_meshes)
+        hipLaunchKernelGGL(k_trace<true>, dim3(bin_blocks(bound)), dim3(BLOCK), 0, s, sc, b, pool, res, previous, block_counts,
+                           count_stride, counters);
+    else
+        hipLaunchKernelGGL(k_trace<false>, dim3(bin_blocks(bound)), dim3(BLOCK), 0, s, sc, b, pool, res, previous, block_counts,
+                           count_stride, counters);
 }
 
-void launch_bin(hipStream_t s, const DevScene& sc, const PathState& ps, const uint32_t* list_in, uint32_t bound, const BinInfo* previous,
-                uint32_t* block_counts, uint32_t count_stride, BinInfo* info, uint32_t* list_out) {
+void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_t bound, const BinInfo* previous, uint32_t* block_counts,
+                uint32_t count_stride, BinInfo* info, uint32_t* list_out) {
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, block_counts, count_stride, sc.class_mask, previous, info);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(bin_blocks(bound)), dim3(BLOCK), 0, s, ps, list_in, previous, block_counts, count_stride,
+    hipLaunchKernelGGL(k_bin_scatter, dim3(bin_blocks(bound)), dim3(BLOCK), 0, s, pool, previous, block_counts, count_stride,
                        sc.class_mask, list_out);
 }
 
 template<int CLS>
-static void launch_shade_t(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathState& ps,
-                           const uint32_t* list, const BinInfo* info) {
-    hipLaunchKernelGGL(k_shade<CLS>, dim3(grid_for(bound, 16384)), dim3(BLOCK), 0, s, sc, b, ps, list, info);
+static void launch_shade_t(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in,
+                           const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info,
+                           unsigned long long* counters) {
+    hipLaunchKernelGGL(k_shade<CLS>, dim3(grid_for(bound, 8192)), dim3(BLOCK), 0, s, sc, b, in, out, res, list, info, counters);
 }
 
-void launch_shade(hipStream_t s, int cls, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathState& ps,
-                  const uint32_t* list, const BinInfo* info) {
+void launch_shade(hipStream_t s, int cls, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in,
+                  const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info,
+                  unsigned long long* counters) {
     switch (cls) {
-        case 0: launch_shade_t<0>(s, bound, sc, b, ps, list, info); break;
-        case 1: launch_shade_t<1>(s, bound, sc, b, ps, list, info); break;
-        case 2: launch_shade_t<2>(s, bound, sc, b, ps, list, info); break;
-        case 3: launch_shade_t<3>(s, bound, sc, b, ps, list, info); break;
-        case 4: launch_shade_t<4>(s, bound, sc, b, ps, list, info); break;
-        case 5: launch_shade_t<5>(s, bound, sc, b, ps, list, info); break;
-        case 6: launch_shade_t<6>(s, bound, sc, b, ps, list, info); break;
-        case 7: launch_shade_t<7>(s, bound, sc, b, ps, list, info); break;
+        case 0: launch_shade_t<0>(s, bound, sc, b, in, out, res, list, info, counters); break;
+        case 1: launch_shade_t<1>(s, bound, sc, b, in, out, res, list, info, counters); break;
+        case 2: launch_shade_t<2>(s, bound, sc, b, in, out, res, list, info, counters); break;
+        case 3: launch_shade_t<3>(s, bound, sc, b, in, out, res, list, info, counters); break;
+        case 4: launch_shade_t<4>(s, bound, sc, b, in, out, res, list, info, counters); break;
+        case 5: launch_shade_t<5>(s, bound, sc, b, in, out, res, list, info, counters); break;
+        case 6: launch_shade_t<6>(s, bound, sc, b, in, out, res, list, info, counters); break;
+        case 7: launch_shade_t<7>(s, bound, sc, b, in, out, res, list, info, counters); break;
         default: break;
     }
 }
 
-void launch_connect(hipStream_t s, uint32_t bound, const DevScene& sc, const PathState& ps, const uint32_t* list, const BinInfo* info,
-                    unsigned long long* ray_counter) {
-    hipLaunchKernelGGL(k_connect, dim3(grid_for(bound, 16384)), dim3(BLOCK), 0, s, sc, ps, list, info, ray_counter);
-}
-
-void launch_accumulate(hipStream_t s, const BatchParams& b, const PathState& ps, double* image, double* position, double* normal,
+void launch_accumulate(hipStream_t s, const BatchParams& b, const SampleResults& res, double* image, double* position, double* normal,
                        unsigned long long* pixel_counters) {
-    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(b.n_pixels, 4096)), dim3(BLOCK), 0, s, b, ps, image, position, normal,
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(b.n_pixels, 4096)), dim3(BLOCK), 0, s, b, res, image, position, normal,
                        pixel_counters);
 }
 
-void launch_gather_samples(hipStream_t s, const BatchParams& b, const PathState& ps, size_t pixel_base, double* color,
+void launch_gather_samples(hipStream_t s, const BatchParams& b, const SampleResults& res, size_t pixel_base, double* color,
                            double* position, double* normal) {
-    hipLaunchKernelGGL(k_gather_samples, dim3(grid_for(b.n_paths, 4096)), dim3(BLOCK), 0, s, b, ps, pixel_base, color, position,
+    hipLaunchKernelGGL(k_gather_samples, dim3(grid_for(b.n_paths, 4096)), dim3(BLOCK), 0, s, b, res, pixel_base, color, position,
                        normal);
 }
 

@@ -6,10 +6,8 @@
 //   * triangles: `tri_hot` holds the three vertices in fp64 (72 B, all the intersection test
 //     reads), `tri_cold` everything shading needs; both in BVH leaf order;
 //   * BVH: 4-wide nodes of 128 B with fp32 boxes rounded outward;
-//   * path state: structure of arrays indexed by slot, two pools used ping-pong so that the
-//     survivors of a bounce are written densely (compaction is fused into the shade kernels);
-//   * per-sample results: structure of arrays indexed by the sample's batch index
-//     sid = sample * pixels_in_batch + pixel, so neighbouring lanes hold neighbouring pixels.
+//   * path records: two pools of 16-byte planes used ping-pong (see PathPool);
+//   * per-sample results indexed by the sample's batch index (see SampleResults).
 #pragma once
 #include <stdint.h>
 
@@ -95,7 +93,8 @@ struct DevCamera {
 
 struct DevScene {
     int32_t n_objects, n_materials, n_media, n_maps;
-    int32_t n_lights, has_triangles;
+    int32_t n_lights, has_triangles; // has_triangles: any triangle or mesh object
+    int32_t has_meshes, _pad0;
     int32_t width, height;
     int32_t max_depth, min_depth, nee, aa;
     int32_t background_medium, background_is_black;
@@ -115,39 +114,51 @@ struct DevScene {
     uint32_t class_mask;                 // material classes present in the scene (+ scatter bit)
 };
 
-// Path state: structure of arrays with one entry per sample of the batch.  The index of a sample,
-// sid = sample * pixels_in_batch + pixel, is also its slot for the whole life of the path: nothing
-// is ever moved.  Kernels reach the live paths through index lists (see kernels.hip).
-struct PathState {
-    double *ox, *oy, *oz;   // ray origin
-    double *dx, *dy, *dz;   // ray direction
-    double *tx, *ty, *tz;   // throughput
-    double *sx, *sy, *sz;   // saved_point (origin of the last non-virtual sampling event)
-    double *spdf;           // scatter_pdf of that event
-    uint32_t* ctr;          // next random-number counter
-    uint32_t* flags;        // depth (13 bits) | ray type << 13 | has_hit_surface << 15 | medium << 16
-    // hit record: written by k_extend, read by k_shade
-    double* hit_t;          // distance to the vertex (surface hit or scatter point)
-    int32_t* hit_obj;       // object index
-    int32_t* hit_prim;      // triangle index (global, leaf order) for triangles / meshes
-    uint8_t* cls;           // queue class of the current vertex; CLASS_DEAD once the path has ended
-    // pending next-event connection: written by k_shade, consumed by k_connect (origin = ox, oy, oz)
-    double *sh_dx, *sh_dy, *sh_dz;
-    double* sh_dist;           // distance to the sampled light point
-    double *sh_cr, *sh_cg, *sh_cb; // contribution before emittance and transmittance
-    uint64_t* sh_key;          // forked random-number key for the march
-    uint32_t* sh_info;         // SHADOW_VALID | medium << 16 | light object index
-    // results (PixelData, app/pathtracer.cpp:20-24)
-    double *cr, *cg, *cb;      // radiance
-    double *px, *py, *pz;      // first-surface position
-    double *nx, *ny, *nz;      // first-surface normal
+// Path records live in two pools used ping-pong.  A pool is a set of planes of 16-byte elements
+// (plane p of record i at base + p * plane_bytes + 16 * i), so a wave reads or writes 1 KiB of
+// consecutive memory per instruction and every record is reached from one base pointer plus a
+// 32-bit offset.  Each bounce's shade kernels read the records of their class through the sorted
+// index list and write the updated records to the other pool at the list position, so the records
+// of the paths still in flight are always packed at the front of the current pool.
+enum Plane : int {
+    PL_RAY0 = 0, // origin.x, origin.y
+    PL_RAY1,     // origin.z, direction.x
+    PL_RAY2,     // direction.y, direction.z
+    PL_THR0,     // throughput.x, throughput.y
+    PL_THR1,     // throughput.z, scatter_pdf of the last non-virtual sampling event
+    PL_SAV0,     // saved_point.x, saved_point.y (origin of that event)
+    PL_SAV1,     // saved_point.z, pending connection: contribution.z
+    PL_COL0,     // radiance gathered so far: r, g
+    PL_COL1,     // radiance b, pending connection: forked random-number key (uint64)
+    PL_IDS,      // uint32 x 4: flags, sample id, next random-number counter, connection info
+    PL_HIT,      // hit distance (double), object index (int32), triangle index (int32, global leaf order)
+    PL_SH0,      // pending connection: direction.x, direction.y
+    PL_SH1,      // direction.z, distance to the sampled light point
+    PL_SH2,      // contribution.x, contribution.y (before emittance and transmittance)
+    N_PLANES
+};
+struct PathPool {
+    char* base;
+    uint64_t plane_bytes; // capacity * 16
+    uint8_t* cls;         // per record: class of the vertex to shade (0..7), or one of the CLASS_* marks
+};
+// flags: depth (13 bits) | ray type << 13 | has_hit_surface << 15 | medium << 16
+// connection info: SHADOW_VALID | medium << 16 | light object index
+
+// Per-sample results (PixelData, app/pathtracer.cpp:20-24), indexed by the sample's batch index
+// sid = sample * pixels_in_batch + pixel, so neighbouring lanes hold neighbouring pixels.
+struct SampleResults {
+    double* color;          // [n][4]: r, g, b, unused; written once, when the path ends
+    double* surface;        // 3 planes of [n][2]: (px, py), (pz, nx), (ny, nz) of the first surface hit
+    uint64_t plane_doubles; // doubles per plane of `surface`
 };
 constexpr uint32_t DEPTH_MASK = 0x1FFFu;
 constexpr uint32_t TYPE_SHIFT = 13;
 constexpr uint32_t FLAG_HAS_HIT = 1u << 15;
 constexpr uint32_t MEDIUM_NONE = 0x7FFFu;
 constexpr uint32_t SHADOW_VALID = 1u << 31;
-constexpr uint8_t CLASS_DEAD = 0xFF;
+constexpr uint8_t CLASS_DEAD = 0xFF; // the path has ended; its record still carries a pending connection
+constexpr uint8_t CLASS_DONE = 0xFE; // ended and flushed to the results: nothing left to do
 
 struct BatchParams {
     int64_t start_idx;    // first pixel
@@ -158,16 +169,16 @@ struct BatchParams {
     uint64_t seed;
 };
 
-// A bounce's list of live paths is binned by class without atomics: k_extend leaves per-block
-// class counts, k_bin_scan turns them into offsets (and this summary), k_bin_scatter writes the
-// class-sorted list.  BIN_CHUNK consecutive list entries belong to one block in all three.
+// A bounce's records are binned by class without atomics: k_trace leaves per-block class counts,
+// k_bin_scan turns them into offsets (and this summary), k_bin_scatter writes the class-sorted
+// index list.  BIN_CHUNK consecutive records belong to one block in all three.
 constexpr int BIN_BLOCK = 256;
 constexpr int BIN_ROUNDS = 8;
 constexpr int BIN_CHUNK = BIN_BLOCK * BIN_ROUNDS;
 struct BinInfo {
     uint32_t start[N_CLASSES]; // first entry of each class segment in the sorted list
     uint32_t count[N_CLASSES];
-    uint32_t total;            // live paths = length of the sorted list
+    uint32_t total;            // length of the sorted list = records the shade kernels write to the other pool
     uint32_t _pad[15];
 };
 

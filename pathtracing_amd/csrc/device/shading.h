@@ -335,6 +335,7 @@ PTK_DEV bool pick_light_point(const DevScene& sc, int shaded_object, const V3& f
 // compute_visibility (src/objects.cpp:470-513) plus sample_light's acceptance test (:558):
 // marches towards the light through surfaces that let direct light pass, multiplying the
 // transmittance of each segment's medium.  Returns emittance * transmittance, or black.
+template<bool MESHES>
 PTK_DEV V3 march_to_light(const DevScene& sc, V3 org, const V3& dir, int medium, int light_index, double distance_to_light,
                           Rng& rng, TraversalStack& st, uint32_t& rays) {
     V3 transmittance = v3(1.0);
@@ -342,7 +343,7 @@ PTK_DEV V3 march_to_light(const DevScene& sc, V3 org, const V3& dir, int medium,
     for (;;) {
         HitInfo h;
         rays++;
-        if (!closest_hit(sc, org, dir, INF, h, st)) return v3(0.0);
+        if (!closest_hit<MESHES>(sc, org, dir, INF, h, st)) return v3(0.0);
         distance += h.t;
         if (medium < 0) medium = sc.background_medium;
         transmittance = transmittance * medium_transmittance(sc.media[medium], h.t);

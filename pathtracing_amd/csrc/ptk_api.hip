@@ -164,14 +164,15 @@ struct PtkScene {
     DeviceBuffers pool_buffers;  // path state, queues, results
     int64_t max_paths = DEFAULT_MAX_PATHS;
     int64_t capacity = 0;
-    PathState state{};
-    uint32_t* lists[2] = {nullptr, nullptr}; // ping-pong index lists of live paths
+    PathPool pools[2] = {};     // path records, ping-pong
+    SampleResults results{};
+    uint32_t* list = nullptr;   // class-sorted record indices of the current bounce
     uint32_t* block_counts = nullptr;        // [N_CLASSES][count_stride]
     uint32_t count_stride = 0;
     BinInfo* d_info = nullptr;  // [2]: summaries of the previous and the current bounce's lists
     BinInfo* h_info = nullptr;  // pinned ring of INFO_RING summaries read back asynchronously
     hipEvent_t info_events[8] = {};
-    unsigned long long* h_rays = nullptr; // pinned [2]
+    unsigned long long* h_rays = nullptr; // pinned [N_COUNTERS]
     unsigned long long* d_ray_counter = nullptr;
     std::vector<int> classes; // queue classes present in the scene
     PtkFilm* host_film = nullptr; // scratch film for ptk_render_host
@@ -185,38 +186,41 @@ int ensure_capacity(PtkScene* s, int64_t paths) {
     if (paths <= s->capacity) return PTK_OK;
     s->pool_buffers.free_all(); // the previous, smaller arrays
     s->capacity = 0;
-    const size_t n = static_cast<size_t>(paths);
+    const size_t n = (static_cast<size_t>(paths) + 255) & ~static_cast<size_t>(255); // planes stay 4 KiB aligned
     DeviceBuffers& b = s->pool_buffers;
-    PathState& p = s->state;
-    double** doubles[] = {&p.ox, &p.oy, &p.oz, &p.dx, &p.dy, &p.dz, &p.tx, &p.ty, &p.tz, &p.sx, &p.sy, &p.sz, &p.spdf, &p.hit_t,
-                          &p.sh_dx, &p.sh_dy, &p.sh_dz, &p.sh_dist, &p.sh_cr, &p.sh_cg, &p.sh_cb, &p.cr, &p.cg, &p.cb, &p.px,
-                          &p.py, &p.pz, &p.nx, &p.ny, &p.nz};
-    for (double** f : doubles) HIP_TRY(b.alloc(f, n));
-    HIP_TRY(b.alloc(&p.ctr, n));
-    HIP_TRY(b.alloc(&p.flags, n));
-    HIP_TRY(b.alloc(&p.hit_obj, n));
-    HIP_TRY(b.alloc(&p.hit_prim, n));
-    HIP_TRY(b.alloc(&p.cls, n));
-    HIP_TRY(b.alloc(&p.sh_key, n));
-    HIP_TRY(b.alloc(&p.sh_info, n));
-    HIP_TRY(b.alloc(&s->lists[0], n));
-    HIP_TRY(b.alloc(&s->lists[1], n));
+    for (PathPool& pool : s->pools) {
+        pool.plane_bytes = n * 16;
+        HIP_TRY(b.alloc(&pool.base, pool.plane_bytes * N_PLANES));
+        HIP_TRY(b.alloc(&pool.cls, n));
+    }
+    HIP_TRY(b.alloc(&s->results.color, n * 4));
+    s->results.plane_doubles = n * 2;
+    HIP_TRY(b.alloc(&s->results.surface, n * 6));
+    HIP_TRY(b.alloc(&s->list, n));
     s->count_stride = (bin_blocks(static_cast<uint32_t>(n)) + 3u) & ~3u; // rows stay 16-byte aligned
     HIP_TRY(b.alloc(&s->block_counts, static_cast<size_t>(s->count_stride) * N_CLASSES));
     s->capacity = paths;
     return PTK_OK;
 }
 
-// bytes the kernels are specified to move per item (path-state, hit, queue and shadow records)
-constexpr uint64_t EXTEND_BYTES_PER_PATH = 4 + 1 + 6 * 8 + 4 + 16 + 1;      // list entry, class, ray, flags in; hit record + class out
-constexpr uint64_t BIN_BYTES_PER_PATH = 4 + 1 + 4;                          // list entry + class in, list entry out
-constexpr uint64_t SHADE_BYTES_PER_PATH = 4 + (13 * 8 + 8) + 16 + 3 * 8 + 4; // list entry, state, hit in; origin + shadow info out
-constexpr uint64_t SHADE_BYTES_PER_SURVIVOR = 10 * 8 + 8;                   // direction .. scatter pdf, counter, flags out
-constexpr uint64_t SHADE_BYTES_PER_SHADOW = 7 * 8 + 8;                      // shadow record out
-constexpr uint64_t CONNECT_BYTES_PER_PATH = 4 + 4;                          // list entry + shadow info in
-constexpr uint64_t CONNECT_BYTES_PER_SHADOW = 3 * 8 + 7 * 8 + 8 + 2 * 24;   // origin + record in, radiance read-modify-write
-constexpr uint64_t GENERATE_BYTES_PER_PATH = 13 * 8 + 8 + 1 + 4 + 9 * 8 + 4; // state, class, shadow info, zeroed results, list out
-constexpr uint64_t ACCUMULATE_BYTES_PER_PATH = 9 * 8;                       // results in
+// Bytes the kernels are specified to move per item (16-byte planes of the path records, see
+// scene_device.h).  Conservative where the host cannot know a count: the write-back of the radiance
+// after a visible connection is not counted.
+constexpr uint64_t TRACE_BYTES_PER_RECORD = 1;                       // class mark in
+constexpr uint64_t TRACE_BYTES_PER_EXTENSION = 16 + 3 * 16 + 16 + 1; // ids + ray in; hit record + class out
+constexpr uint64_t TRACE_BYTES_PER_CONNECTION = 6 * 16;              // radiance, connection record in
+constexpr uint64_t TRACE_BYTES_PER_PATH = 32;                        // radiance flushed to the results, once
+constexpr uint64_t BIN_BYTES_PER_RECORD = 1;                         // class in
+constexpr uint64_t BIN_BYTES_PER_VERTEX = 4;                         // list entry out
+constexpr uint64_t SHADE_BYTES_PER_VERTEX = 4 + 11 * 16;             // list entry, record in
+constexpr uint64_t SHADE_BYTES_PER_KEPT = 6 * 16 + 1;                // origin, saved.z, radiance, ids, class out
+constexpr uint64_t SHADE_BYTES_PER_FINISHED = 32 + 1;                // radiance flushed, class out
+constexpr uint64_t SHADE_BYTES_PER_CONNECTION = 3 * 16;              // connection record out
+constexpr uint64_t SHADE_BYTES_PER_SURVIVOR = 4 * 16;                // direction, throughput, saved point out
+constexpr uint64_t SHADE_BYTES_PER_PATH = 3 * 16;                    // first-surface position and normal, once
+constexpr uint64_t GENERATE_BYTES_PER_PATH = 10 * 16 + 1 + 3 * 16;   // record, class, zeroed surface results out
+constexpr uint64_t ACCUMULATE_BYTES_PER_PATH = 32 + 3 * 16;          // results in
+constexpr int N_COUNTERS = 4;
 
 struct EventTimer {
     PtkScene* s;
@@ -249,9 +253,9 @@ struct EventTimer {
             float ms = 0;
             (void) hipEventElapsedTime(&ms, s->events[sp.second.first], s->events[sp.second.second]);
             switch (sp.first) {
-                case 0: s->stats.extend_ms += ms; break;
+                case 0: s->stats.trace_ms += ms; break;
                 case 1: s->stats.shade_ms += ms; break;
-                case 2: s->stats.connect_ms += ms; break;
+                case 2: s->stats.bin_ms += ms; break;
                 default: s->stats.other_ms += ms; break;
             }
         }
@@ -261,25 +265,24 @@ struct EventTimer {
 };
 
 // Traces one batch (all samples of a contiguous pixel range) to completion; per-sample results
-// are left in s->state.
+// are left in s->results.
 //
-// The host queues bounces without waiting for their counts: kernels read list lengths from device
-// memory, grids are sized by the newest count the host has seen (lengths only shrink), and the
+// The host queues bounces without waiting for their counts: kernels read record counts from device
+// memory, grids are sized by the newest count the host has seen (counts only shrink), and the
 // per-bounce summaries come back through a ring of pinned slots that is polled, not waited on.
 int trace_batch(PtkScene* s, const BatchParams& b) {
     EventTimer timer{s};
     PtkStats& st = s->stats;
     timer.begin(3);
-    launch_generate(g_stream, s->dev, b, s->state, s->lists[0], &s->d_info[1]);
+    launch_generate(g_stream, s->dev, b, s->pools[0], s->results, &s->d_info[1]);
     timer.end();
     st.paths += b.n_paths;
     st.algorithmic_bytes += GENERATE_BYTES_PER_PATH * b.n_paths;
-    const bool nee = s->settings.enable_next_event_estimation != 0;
-    HIP_TRY(hipMemsetAsync(s->d_ray_counter, 0, 2 * sizeof(unsigned long long), g_stream));
+    HIP_TRY(hipMemsetAsync(s->d_ray_counter, 0, N_COUNTERS * sizeof(unsigned long long), g_stream));
 
-    uint32_t bound = b.n_paths;   // newest known upper bound of the live-path count
-    uint64_t list_length = b.n_paths; // length of the list the oldest unretired bounce consumed
-    uint64_t sum_lists = 0, sum_shaded = 0;
+    uint32_t bound = b.n_paths;     // newest known upper bound of the record count
+    uint64_t records = b.n_paths;   // records the oldest unretired bounce walked
+    uint64_t sum_records = 0, sum_shaded = 0;
     int launched = 0, retired = 0;
     bool finished = false;
     auto retire = [&](bool wait) -> int { // consumes completed summaries in order
@@ -288,65 +291,65 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
             if (wait) HIP_TRY(hipEventSynchronize(s->info_events[slot]));
             else if (hipEventQuery(s->info_events[slot]) != hipSuccess) break;
             const uint32_t total = s->h_info[slot].total;
-            sum_lists += list_length;
+            sum_records += records;
             sum_shaded += total;
-            list_length = total;
+            records = total;
             bound = total;
             if (total == 0) finished = true;
             retired++;
         }
         return PTK_OK;
     };
-    for (int depth = 0; depth <= s->settings.max_recursion_depth && !finished; depth++) {
+    // Bounce `depth` shades the vertices at that depth; one more round than the deepest vertex
+    // finishes the connections the last shade left pending.
+    for (int depth = 0; depth <= s->settings.max_recursion_depth + 1 && !finished; depth++) {
         if (launched - retired == INFO_RING) { // ring full: wait for the oldest summary
             HIP_TRY(hipEventSynchronize(s->info_events[retired % INFO_RING]));
         }
         int rc = retire(false);
         if (rc != PTK_OK) return rc;
         if (finished) break;
-        const int cur = depth & 1;
+        const PathPool& current = s->pools[depth & 1];
+        const PathPool& next = s->pools[(depth + 1) & 1];
         BinInfo* previous = &s->d_info[(depth + 1) & 1];
         BinInfo* info = &s->d_info[depth & 1];
         timer.begin(0);
-        launch_extend(g_stream, s->dev, b, s->state, s->lists[cur], bound, previous, s->block_counts, s->count_stride,
-                      s->d_ray_counter + 1);
+        launch_trace(g_stream, s->dev, b, current, s->results, bound, previous, s->block_counts, s->count_stride, s->d_ray_counter);
         timer.end();
-        timer.begin(3);
-        launch_bin(g_stream, s->dev, s->state, s->lists[cur], bound, previous, s->block_counts, s->count_stride, info, s->lists[cur ^ 1]);
+        timer.begin(2);
+        launch_bin(g_stream, s->dev, current, bound, previous, s->block_counts, s->count_stride, info, s->list);
         timer.end();
         timer.begin(1);
-        for (int cls : s->classes) launch_shade(g_stream, cls, bound, s->dev, b, s->state, s->lists[cur ^ 1], info);
+        for (int cls : s->classes)
+            launch_shade(g_stream, cls, bound, s->dev, b, current, next, s->results, s->list, info, s->d_ray_counter);
         timer.end();
-        if (nee) {
-            timer.begin(2);
-            launch_connect(g_stream, bound, s->dev, s->state, s->lists[cur ^ 1], info, s->d_ray_counter);
-            timer.end();
-        }
         const int slot = launched % INFO_RING;
         HIP_TRY(hipMemcpyAsync(&s->h_info[slot], info, sizeof(BinInfo), hipMemcpyDeviceToHost, g_stream));
         HIP_TRY(hipEventRecord(s->info_events[slot], g_stream));
         launched++;
         st.bounce_launch_rounds++;
-        st.extend_launches++;
+        st.trace_launches++;
+        st.bin_launches += 2;
         st.shade_launches += s->classes.size();
-        st.connect_launches += nee ? 1 : 0;
     }
-    HIP_TRY(hipMemcpyAsync(s->h_rays, s->d_ray_counter, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(s->h_rays, s->d_ray_counter, N_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, g_stream));
     int rc = retire(true);
     if (rc != PTK_OK) return rc;
     HIP_TRY(hipStreamSynchronize(g_stream));
-    const uint64_t shadows = s->h_rays[0];
-    st.shadow_rays += shadows;
-    st.extension_rays += s->h_rays[1];
+    const uint64_t segments = s->h_rays[0], extensions = s->h_rays[1], connections = s->h_rays[2], done_in_shade = s->h_rays[3];
+    st.shadow_rays += segments;
+    st.extension_rays += extensions;
     st.vertices += sum_shaded;
-    const uint64_t eb = EXTEND_BYTES_PER_PATH * sum_lists;
-    const uint64_t bb = BIN_BYTES_PER_PATH * sum_lists;
-    const uint64_t sb = (SHADE_BYTES_PER_PATH + SHADE_BYTES_PER_SURVIVOR) * sum_shaded + SHADE_BYTES_PER_SHADOW * shadows;
-    const uint64_t cb = nee ? CONNECT_BYTES_PER_PATH * sum_shaded + CONNECT_BYTES_PER_SHADOW * shadows : 0;
-    st.extend_bytes += eb;
+    const uint64_t tb = TRACE_BYTES_PER_RECORD * sum_records + TRACE_BYTES_PER_EXTENSION * extensions +
+                        TRACE_BYTES_PER_CONNECTION * connections + TRACE_BYTES_PER_PATH * (b.n_paths - done_in_shade);
+    const uint64_t bb = BIN_BYTES_PER_RECORD * sum_records + BIN_BYTES_PER_VERTEX * sum_shaded;
+    const uint64_t sb = SHADE_BYTES_PER_VERTEX * sum_shaded + SHADE_BYTES_PER_KEPT * (sum_shaded - done_in_shade) +
+                        SHADE_BYTES_PER_FINISHED * done_in_shade + SHADE_BYTES_PER_CONNECTION * connections +
+                        SHADE_BYTES_PER_SURVIVOR * (extensions - b.n_paths) + SHADE_BYTES_PER_PATH * b.n_paths;
+    st.trace_bytes += tb;
     st.shade_bytes += sb;
-    st.connect_bytes += cb;
-    st.algorithmic_bytes += eb + bb + sb + cb;
+    st.bin_bytes += bb;
+    st.algorithmic_bytes += tb + bb + sb;
     timer.collect();
     return PTK_OK;
 }
@@ -682,6 +685,9 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     dev.n_maps = d->n_maps;
     dev.n_lights = static_cast<int32_t>(lights.size());
     dev.has_triangles = !tri_hot.empty();
+    dev.has_meshes = 0;
+    for (const DevObject& o : objects)
+        if (o.type == PTK_OBJ_MESH) dev.has_meshes = 1;
     dev.width = d->settings.width;
     dev.height = d->settings.height;
     dev.max_depth = d->settings.max_recursion_depth;
@@ -707,9 +713,9 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     HIP_TRY(buf.upload(&dev.light_cumulative_area, light_area));
     HIP_TRY(buf.upload(&dev.light_tri_index, light_tri));
     HIP_TRY(buf.alloc(&s->d_info, 2));
-    HIP_TRY(buf.alloc(&s->d_ray_counter, 2)); // [0] shadow rays, [1] extension rays
+    HIP_TRY(buf.alloc(&s->d_ray_counter, N_COUNTERS)); // see launch_trace
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_info), INFO_RING * sizeof(BinInfo), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_rays), 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_rays), N_COUNTERS * sizeof(unsigned long long), hipHostMallocDefault));
     for (int i = 0; i < INFO_RING; i++) HIP_TRY(hipEventCreateWithFlags(&s->info_events[i], hipEventDisableTiming));
     *out = s.release();
     return PTK_OK;
@@ -770,7 +776,7 @@ int ptk_trace_samples(PtkScene* s, const PtkRenderJob* job, double* color, doubl
     if (position) HIP_TRY(tmp.alloc(&d_pos, total));
     if (normal) HIP_TRY(tmp.alloc(&d_nrm, total));
     rc = for_each_batch(s, job, [&](const BatchParams& b, int64_t pixel_base) {
-        launch_gather_samples(g_stream, b, s->state, static_cast<size_t>(pixel_base), d_color, d_pos, d_nrm);
+        launch_gather_samples(g_stream, b, s->results, static_cast<size_t>(pixel_base), d_color, d_pos, d_nrm);
         HIP_TRY(hipGetLastError());
         return static_cast<int>(PTK_OK);
     });
@@ -880,7 +886,7 @@ int ptk_render(PtkScene* s, PtkFilm* film, const PtkRenderJob* job) {
     if (!film || film->width != s->settings.width || film->height != s->settings.height)
         return fail(PTK_ERR_INVALID, "ptk_render: film size does not match the scene");
     return for_each_batch(s, job, [&](const BatchParams& b, int64_t) {
-        launch_accumulate(g_stream, b, s->state, film->image, film->position, film->normal, film->counters);
+        launch_accumulate(g_stream, b, s->results, film->image, film->position, film->normal, film->counters);
         HIP_TRY(hipGetLastError());
         s->stats.algorithmic_bytes += ACCUMULATE_BYTES_PER_PATH * b.n_paths;
         return static_cast<int>(PTK_OK);
