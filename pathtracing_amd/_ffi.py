@@ -149,7 +149,8 @@ def load_host_library():
 
 
 def load_device_library():
-    path = os.path.join(HERE, "libptk.so")
+    # PTK_DEVICE_LIBRARY selects another build of the same library (kernel tuning experiments)
+    path = os.environ.get("PTK_DEVICE_LIBRARY") or os.path.join(HERE, "libptk.so")
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: the HIP library must be built (there is no CPU fallback); "
                            "run `python -c 'import __graft_entry__ as g; g.build()'`")

@@ -163,14 +163,15 @@ struct HitInfo {
 
 // find_closest_hit (src/objects.cpp:414-442) without the attribute computation: the linear scan
 // over top-level objects with the shrinking t_max; first object wins exact ties.
-// MESHES = false compiles the BVH traversal (and with it the stack) out, for scenes without meshes.
-template<bool MESHES>
+// TRIS = false compiles the triangle test and the BVH traversal (and with it the stack) out, for
+// scenes made of spheres, planes and rectangles only.
+template<bool TRIS>
 PTK_DEV bool closest_hit(const DevScene& sc, const V3& org, const V3& dir, double t_max, HitInfo& hit, TraversalStack& st) {
     hit.t = INF;
     hit.obj = -1;
     hit.prim = 0;
     RayPrep rp{};
-    if (sc.has_triangles) rp = prepare_ray(dir);
+    if (TRIS) rp = prepare_ray(dir);
     const double dir_dot_org = dot(dir, org);
     double limit = t_max; // ray.t_max
     // The object table is read through the constant address space: the index is wave-uniform, so the
@@ -202,11 +203,11 @@ PTK_DEV bool closest_hit(const DevScene& sc, const V3& org, const V3& dir, doubl
                 }
             }
         }
-        else if (o.type == PTK_OBJ_TRIANGLE) {
+        else if (TRIS && o.type == PTK_OBJ_TRIANGLE) {
             success = triangle_hit(sc.tri_hot[o.first_tri], org, rp, limit, d);
             prim = static_cast<int>(o.first_tri);
         }
-        else if (MESHES) { // mesh
+        else if (TRIS) { // mesh
             double tb = limit;
             int pb = -1;
             mesh_closest_hit(sc, o.bvh_root, o.first_tri, org, dir, rp, tb, pb, st);
@@ -234,9 +235,10 @@ PTK_DEV V3 tri_barycentric(const TriCold& t, const V3& p) { // compute_barycentr
     return v3(l1, l2, 1.0 - l1 - l2);
 }
 
+template<bool TRIS>
 PTK_DEV V3 object_normal(const DevScene& sc, const DevObject& o, const V3& p, int prim) { // get_normal_vector
     if (o.type == PTK_OBJ_SPHERE) return normalize(p - v3(o.px, o.py, o.pz));
-    if (o.type == PTK_OBJ_PLANE || o.type == PTK_OBJ_RECTANGLE) return v3(o.nx, o.ny, o.nz);
+    if (!TRIS || o.type == PTK_OBJ_PLANE || o.type == PTK_OBJ_RECTANGLE) return v3(o.nx, o.ny, o.nz);
     const TriCold& t = sc.tri_cold[prim];
     if (t.smooth) { // :334-337
         V3 b = tri_barycentric(t, p);
@@ -245,6 +247,7 @@ PTK_DEV V3 object_normal(const DevScene& sc, const DevObject& o, const V3& p, in
     return v3(t.normal);
 }
 
+template<bool TRIS>
 PTK_DEV void object_uv(const DevScene& sc, const DevObject& o, const V3& p, int prim, double& u, double& v) { // get_UV
     if (o.type == PTK_OBJ_SPHERE) { // :96-104
         V3 unit = (p - v3(o.px, o.py, o.pz)) / o.radius;
@@ -256,7 +259,7 @@ PTK_DEV void object_uv(const DevScene& sc, const DevObject& o, const V3& p, int 
         u = 1 - dot(s, v3(o.v1x, o.v1y, o.v1z)) - 0.5;
         v = 1 - dot(s, v3(o.v2x, o.v2y, o.v2z)) - 0.5;
     }
-    else if (o.type == PTK_OBJ_RECTANGLE) { // :230-235
+    else if (!TRIS || o.type == PTK_OBJ_RECTANGLE) { // :230-235
         V3 s = p - v3(o.px, o.py, o.pz);
         u = 1 - dot(s, v3(o.v1x, o.v1y, o.v1z)) / o.L1 - 0.5;
         v = 1 - dot(s, v3(o.v2x, o.v2y, o.v2z)) / o.L2 - 0.5;

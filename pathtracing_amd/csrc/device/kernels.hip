@@ -29,6 +29,15 @@
 namespace ptk {
 
 constexpr int BLOCK = 256;
+// Register budgets: the kernels are compiled for a fixed number of waves per SIMD (512 registers
+// per lane and SIMD are shared by the resident waves).
+#ifndef PTK_TRACE_WAVES
+#define PTK_TRACE_WAVES 4
+#endif
+#ifndef PTK_SHADE_WAVES
+#define PTK_SHADE_WAVES 3
+#endif
+#define PTK_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 static_assert(BLOCK == BIN_BLOCK, "k_extend and the bin kernels share their block geometry");
 
 PTK_DEV TraversalStack make_stack(StackEntry* lds) {
@@ -151,12 +160,14 @@ __global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, 
 // closest hit, miss handling.  Block b owns records [b * BIN_CHUNK, (b + 1) * BIN_CHUNK) and leaves
 // its per-class counts in block_counts[class * count_stride + b].
 // counters: [0] visibility-march segments, [1] extension rays, [2] connections marched.
-template<bool MESHES>
-__global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, BatchParams b, PathPool pool, SampleResults res, const BinInfo* previous,
+// TRIS: the scene has triangles or meshes; UV: some material reads a map larger than 1x1 (texture
+// coordinates are needed).  Scenes without them get kernels without that code and its registers.
+template<bool TRIS, bool UV>
+__global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(TRIS ? 2 : PTK_TRACE_WAVES) void k_trace(DevScene sc, BatchParams b, PathPool pool, SampleResults res, const BinInfo* previous,
                                                  uint32_t* block_counts, uint32_t count_stride, unsigned long long* counters) {
     const uint32_t n = previous->total; // records the previous bounce's shade kernels wrote
     if (blockIdx.x * BIN_CHUNK >= n) return;
-    __shared__ StackEntry lds_stack[MESHES ? LDS_STACK_DEPTH * BLOCK : 1];
+    __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1];
     __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
     __shared__ uint32_t wave_rays[BLOCK / 64][3];
     TraversalStack st = make_stack(lds_stack);
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, BatchParams b, Pat
                 const double2 v1 = ld2(pool, PL_SAV1, idx);
                 Rng rng{double_as_key(c1.y), 0};
                 connections++;
-                V3 visible = march_to_light<MESHES>(sc, org, v3(s0.x, s0.y, s1.x), static_cast<int>((ids.w >> 16) & 0x7FFFu),
+                V3 visible = march_to_light<TRIS, UV>(sc, org, v3(s0.x, s0.y, s1.x), static_cast<int>((ids.w >> 16) & 0x7FFFu),
                                                     static_cast<int>(ids.w & 0xFFFFu), s1.y, rng, st, segments);
                 if (visible.x != 0 || visible.y != 0 || visible.z != 0) {
                     c0.x += s2.x * visible.x;
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, BatchParams b, Pat
                     if (ext != 0) scatter_distance = -log(rng.u01()) / ext;
                 }
                 HitInfo h;
-                bool found = closest_hit<MESHES>(sc, org, dir, scatter_distance, h, st);
+                bool found = closest_hit<TRIS>(sc, org, dir, scatter_distance, h, st);
                 extensions++;
                 if (!found && scatter_distance == INF) {
                     // color += throughput * background_color; the path ends
@@ -396,8 +407,8 @@ __global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathPool pool, const BinI
 // Loop body of raytrace (app/pathtracer.cpp:69-171) for the vertices of one class.  Reads record
 // list[first + j] of `in`, writes record first + j of `out`.
 // counters[3]: records that needed nothing further (path ended, no connection pending).
-template<int CLS>
-__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, BatchParams b, PathPool in, PathPool out, SampleResults res,
+template<int CLS, bool TRIS, bool UV>
+__global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_SHADE_WAVES) void k_shade(DevScene sc, BatchParams b, PathPool in, PathPool out, SampleResults res,
                                                  const uint32_t* list, const BinInfo* info, unsigned long long* counters) {
     const uint32_t n = info->count[CLS];
     const uint32_t first = info->start[CLS];
@@ -452,7 +463,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, BatchParams b, Pat
             n_dir = sample_spherical(rng);
             if (sc.nee) {
                 LightSample ls;
-                if (pick_light_point(sc, -1, point, ls, rng)) {
+                if (pick_light_point<TRIS>(sc, -1, point, ls, rng)) {
                     double weight = mis_weight(ls.light_pdf, PHASE_ISOTROPIC);
                     sh_contrib = thr * (weight * PHASE_ISOTROPIC / ls.light_pdf * static_cast<double>(sc.n_lights));
                     sh_dir = ls.direction;
@@ -478,12 +489,12 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, BatchParams b, Pat
             s.incident = dir;
             s.obj = obj;
             s.prim = prim;
-            V3 normal = object_normal(sc, o, point, prim);
+            V3 normal = object_normal<TRIS>(sc, o, point, prim);
             s.outside = dot(dir, normal) < 0;
             s.normal = s.outside ? normal : -normal;
-            s.use_uv = m.needs_uv != 0;
+            s.use_uv = UV && m.needs_uv != 0;
             s.u = s.v = 0;
-            if (s.use_uv) object_uv(sc, o, point, prim, s.u, s.v);
+            if (s.use_uv) object_uv<TRIS>(sc, o, point, prim, s.u, s.v);
 
             if (!has_hit) {
                 surface_plane(res, 0)[sid] = make_double2(point.x, point.y);
@@ -495,7 +506,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, BatchParams b, Pat
             if (m.is_light) { // :106-119
                 double weight = 1;
                 if (sc.nee && depth != 0 && !is_specular)
-                    weight = mis_weight(scatter_pdf, object_light_pdf(sc, o, point, saved, prim));
+                    weight = mis_weight(scatter_pdf, object_light_pdf<TRIS>(sc, o, point, saved, prim));
                 V3 add = material_emittance(sc, m, s.use_uv, s.u, s.v) * weight * thr;
                 c0.x += add.x;
                 c0.y += add.y;
@@ -503,7 +514,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, BatchParams b, Pat
             }
             if (sc.nee) { // sample_light up to the march (src/objects.cpp:515-551, 562-578)
                 LightSample ls;
-                if (pick_light_point(sc, obj, point, ls, rng)) {
+                if (pick_light_point<TRIS>(sc, obj, point, ls, rng)) {
                     V3 brdf = material_eval<CLS>(sc, m, s, ls.direction, rng);
                     if (len2(brdf) != 0) {
                         double pdf = material_pdf<CLS>(sc, m, s, ls.direction);
@@ -660,7 +671,7 @@ __global__ __launch_bounds__(BLOCK) void k_primary(DevScene sc, BatchParams b, i
         if (found) {
             const DevObject& o = sc.objects[h.obj];
             point = org + dir * h.t;
-            n = object_normal(sc, o, point, h.prim);
+            n = object_normal<true>(sc, o, point, h.prim);
             if (!(dot(dir, n) < 0)) n = -n;
             if (o.type == PTK_OBJ_MESH) prim = sc.tri_cold[h.prim].face_index;
         }
@@ -696,12 +707,18 @@ void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, co
 
 void launch_trace(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathPool& pool, const SampleResults& res, uint32_t bound,
                   const BinInfo* previous, uint32_t* block_counts, uint32_t count_stride, unsigned long long* counters) {
-    if (sc.has_meshes)
-        hipLaunchKernelGGL(k_trace<true>, dim3(bin_blocks(bound)), dim3(BLOCK), 0, s, sc, b, pool, res, previous, block_counts,
-                           count_stride, counters);
-    else
-        hipLaunchKernelGGL(k_trace<false>, dim3(bin_blocks(bound)), dim3(BLOCK), 0, s, sc, b, pool, res, previous, block_counts,
-                           count_stride, counters);
+    const dim3 grid(bin_blocks(bound)), block(BLOCK);
+#define PTK_LAUNCH_TRACE(T, U) \
+    hipLaunchKernelGGL((k_trace<T, U>), grid, block, 0, s, sc, b, pool, res, previous, block_counts, count_stride, counters)
+    if (sc.has_triangles) {
+        if (sc.needs_uv) PTK_LAUNCH_TRACE(true, true);
+        else PTK_LAUNCH_TRACE(true, false);
+    }
+    else {
+        if (sc.needs_uv) PTK_LAUNCH_TRACE(false, true);
+        else PTK_LAUNCH_TRACE(false, false);
+    }
+#undef PTK_LAUNCH_TRACE
 }
 
 void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_t bound, const BinInfo* previous, uint32_t* block_counts,
@@ -715,7 +732,17 @@ template<int CLS>
 static void launch_shade_t(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in,
                            const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info,
                            unsigned long long* counters) {
-    hipLaunchKernelGGL(k_shade<CLS>, dim3(grid_for(bound, 8192)), dim3(BLOCK), 0, s, sc, b, in, out, res, list, info, counters);
+    const dim3 grid(grid_for(bound, 8192)), block(BLOCK);
+#define PTK_LAUNCH_SHADE(T, U) hipLaunchKernelGGL((k_shade<CLS, T, U>), grid, block, 0, s, sc, b, in, out, res, list, info, counters)
+    if (sc.has_triangles) {
+        if (sc.needs_uv) PTK_LAUNCH_SHADE(true, true);
+        else PTK_LAUNCH_SHADE(true, false);
+    }
+    else {
+        if (sc.needs_uv) PTK_LAUNCH_SHADE(false, true);
+        else PTK_LAUNCH_SHADE(false, false);
+    }
+#undef PTK_LAUNCH_SHADE
 }
 
 void launch_shade(hipStream_t s, int cls, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in,

@@ -94,7 +94,8 @@ struct DevCamera {
 struct DevScene {
     int32_t n_objects, n_materials, n_media, n_maps;
     int32_t n_lights, has_triangles; // has_triangles: any triangle or mesh object
-    int32_t has_meshes, _pad0;
+    int32_t has_meshes;
+    int32_t needs_uv; // some material reads a map larger than 1x1
     int32_t width, height;
     int32_t max_depth, min_depth, nee, aa;
     int32_t background_medium, background_is_black;

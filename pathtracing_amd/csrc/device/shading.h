@@ -216,25 +216,27 @@ PTK_DEV V3 medium_emission(const DevMedium& m) { // :66-73
 constexpr double PHASE_ISOTROPIC = 1.0 / (4 * PI); // :21-23
 
 // ---- lights -----------------------------------------------------------------------------------
+template<bool TRIS>
 PTK_DEV double area_to_angle_factor(const DevScene& sc, const DevObject& o, const V3& surface_point, const V3& from,
                                     int prim) { // Object::area_to_angle_PDF_factor src/objects.cpp:68-76
-    V3 normal = object_normal(sc, o, surface_point, prim);
+    V3 normal = object_normal<TRIS>(sc, o, surface_point, prim);
     V3 difference = from - surface_point;
     return fabs(dot(normal, normalize(difference)) / len2(difference));
 }
 
+template<bool TRIS>
 PTK_DEV double object_light_pdf(const DevScene& sc, const DevObject& o, const V3& surface_point, const V3& from, int prim) {
     if (o.type == PTK_OBJ_SPHERE) { // :130-138
         double distance = len(from - v3(o.px, o.py, o.pz));
-        if (distance <= o.radius) return 1.0 / (o.area * area_to_angle_factor(sc, o, surface_point, from, 0));
+        if (distance <= o.radius) return 1.0 / (o.area * area_to_angle_factor<TRIS>(sc, o, surface_point, from, 0));
         double q = o.radius / distance;
         double cos_theta_max = sqrt(1 - q * q);
         return 1.0 / (2.0 * PI * (1 - cos_theta_max));
     }
     if (o.type == PTK_OBJ_PLANE) return 0.0; // :217-219
-    if (o.type == PTK_OBJ_MESH)              // src/objectunion.cpp:132-135
-        return 1.0 / (o.mesh_light_area * area_to_angle_factor(sc, o, surface_point, from, prim));
-    return fabs(1.0 / (o.area * area_to_angle_factor(sc, o, surface_point, from, prim))); // :78-80, :263-265
+    if (TRIS && o.type == PTK_OBJ_MESH)      // src/objectunion.cpp:132-135
+        return 1.0 / (o.mesh_light_area * area_to_angle_factor<TRIS>(sc, o, surface_point, from, prim));
+    return fabs(1.0 / (o.area * area_to_angle_factor<TRIS>(sc, o, surface_point, from, prim))); // :78-80, :263-265
 }
 
 PTK_DEV V3 triangle_random_point(const TriHot& t, Rng& rng) { // :408-412
@@ -262,13 +264,14 @@ PTK_DEV int mesh_random_primitive(const DevScene& sc, const DevObject& o, Rng& r
     return sc.light_tri_index[o.light_table + index];
 }
 
+template<bool TRIS>
 PTK_DEV V3 random_light_point(const DevScene& sc, const DevObject& o, const V3& from, double& pdf, Rng& rng) {
     if (o.type == PTK_OBJ_SPHERE) { // :140-166
         V3 centre = v3(o.px, o.py, o.pz);
         double distance = len(from - centre);
         if (distance <= o.radius) {
             V3 p = sample_spherical(rng) * o.radius + centre;
-            pdf = object_light_pdf(sc, o, p, from, 0);
+            pdf = object_light_pdf<TRIS>(sc, o, p, from, 0);
             return p;
         }
         double q = o.radius / distance;
@@ -294,18 +297,18 @@ PTK_DEV V3 random_light_point(const DevScene& sc, const DevObject& o, const V3& 
         double r1 = rng.uniform(-o.L1 / 2, o.L1 / 2);
         double r2 = rng.uniform(-o.L2 / 2, o.L2 / 2);
         V3 p = v3(o.v1x, o.v1y, o.v1z) * r1 + v3(o.v2x, o.v2y, o.v2z) * r2 + v3(o.px, o.py, o.pz);
-        pdf = object_light_pdf(sc, o, p, from, 0);
+        pdf = object_light_pdf<TRIS>(sc, o, p, from, 0);
         return p;
     }
-    if (o.type == PTK_OBJ_TRIANGLE) {
+    if (TRIS && o.type == PTK_OBJ_TRIANGLE) {
         V3 p = triangle_random_point(sc.tri_hot[o.first_tri], rng);
-        pdf = object_light_pdf(sc, o, p, from, static_cast<int>(o.first_tri));
+        pdf = object_light_pdf<TRIS>(sc, o, p, from, static_cast<int>(o.first_tri));
         return p;
     }
-    if (o.type == PTK_OBJ_MESH) { // src/objectunion.cpp:137-142
+    if (TRIS && o.type == PTK_OBJ_MESH) { // src/objectunion.cpp:137-142
         int tri = mesh_random_primitive(sc, o, rng);
         V3 p = triangle_random_point(sc.tri_hot[tri], rng);
-        pdf = object_light_pdf(sc, o, p, from, tri);
+        pdf = object_light_pdf<TRIS>(sc, o, p, from, tri);
         return p;
     }
     pdf = 0; // plane: Object::random_light_point with the base surface point, pdf 0
@@ -320,11 +323,12 @@ struct LightSample {
     double distance, light_pdf;
 };
 
+template<bool TRIS>
 PTK_DEV bool pick_light_point(const DevScene& sc, int shaded_object, const V3& from, LightSample& ls, Rng& rng) {
     if (sc.n_lights == 0) return false;                                   // sample_random_light :444-462
     ls.light_index = sc.lights[rng.integer(0, sc.n_lights)];
     if (ls.light_index == shaded_object) return false;
-    V3 p = random_light_point(sc, sc.objects[ls.light_index], from, ls.light_pdf, rng);
+    V3 p = random_light_point<TRIS>(sc, sc.objects[ls.light_index], from, ls.light_pdf, rng);
     if (ls.light_pdf == 0) return false;
     V3 d = p - from;
     ls.distance = len(d);
@@ -335,7 +339,7 @@ PTK_DEV bool pick_light_point(const DevScene& sc, int shaded_object, const V3& f
 // compute_visibility (src/objects.cpp:470-513) plus sample_light's acceptance test (:558):
 // marches towards the light through surfaces that let direct light pass, multiplying the
 // transmittance of each segment's medium.  Returns emittance * transmittance, or black.
-template<bool MESHES>
+template<bool TRIS, bool UV>
 PTK_DEV V3 march_to_light(const DevScene& sc, V3 org, const V3& dir, int medium, int light_index, double distance_to_light,
                           Rng& rng, TraversalStack& st, uint32_t& rays) {
     V3 transmittance = v3(1.0);
@@ -343,7 +347,7 @@ PTK_DEV V3 march_to_light(const DevScene& sc, V3 org, const V3& dir, int medium,
     for (;;) {
         HitInfo h;
         rays++;
-        if (!closest_hit<MESHES>(sc, org, dir, INF, h, st)) return v3(0.0);
+        if (!closest_hit<TRIS>(sc, org, dir, INF, h, st)) return v3(0.0);
         distance += h.t;
         if (medium < 0) medium = sc.background_medium;
         transmittance = transmittance * medium_transmittance(sc.media[medium], h.t);
@@ -351,16 +355,16 @@ PTK_DEV V3 march_to_light(const DevScene& sc, V3 org, const V3& dir, int medium,
         const DevMaterial& m = sc.materials[o.material];
         V3 point = org + dir * h.t;
         Surface s;
-        s.use_uv = m.needs_uv != 0;
+        s.use_uv = UV && m.needs_uv != 0;
         s.u = s.v = 0;
-        if (s.use_uv) object_uv(sc, o, point, h.prim, s.u, s.v);
+        if (s.use_uv) object_uv<TRIS>(sc, o, point, h.prim, s.u, s.v);
         if (h.obj == light_index) {
             V3 emittance = material_emittance(sc, m, s.use_uv, s.u, s.v);
             if (fabs(distance_to_light - distance) > EPSILON) return v3(0.0);
             return emittance * transmittance;
         }
         if (!allow_direct_light(sc, m, s, rng)) return v3(0.0);
-        V3 normal = object_normal(sc, o, point, h.prim);
+        V3 normal = object_normal<TRIS>(sc, o, point, h.prim);
         bool outside = dot(dir, normal) < 0;
         org = point;
         medium = outside ? m.internal_medium : m.external_medium;

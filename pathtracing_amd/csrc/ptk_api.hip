@@ -686,6 +686,9 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     dev.n_lights = static_cast<int32_t>(lights.size());
     dev.has_triangles = !tri_hot.empty();
     dev.has_meshes = 0;
+    dev.needs_uv = 0;
+    for (const DevMaterial& m : materials)
+        if (m.needs_uv) dev.needs_uv = 1;
     for (const DevObject& o : objects)
         if (o.type == PTK_OBJ_MESH) dev.has_meshes = 1;
     dev.width = d->settings.width;
