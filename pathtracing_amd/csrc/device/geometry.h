@@ -159,10 +159,24 @@ struct HitInfo {
     double t;
     int obj;
     int prim; // global triangle index (leaf order) for triangles and meshes, 0 otherwise
+    int cls;  // class of the object's material
 };
 
+// One object's DevShape through the constant address space: the index is wave-uniform, so the
+// record arrives in SGPRs by scalar loads instead of costing vector loads and registers per lane.
+PTK_DEV void load_shape(const PTK_CONSTANT DevShape* p, DevShape& s) {
+#pragma unroll
+    for (int k = 0; k < 14; k++) s.f[k] = p->f[k];
+    s.type = p->type;
+    s.cls = p->cls;
+    s.first_tri = p->first_tri;
+    s.bvh_root = p->bvh_root;
+}
+
 // find_closest_hit (src/objects.cpp:414-442) without the attribute computation: the linear scan
-// over top-level objects with the shrinking t_max; first object wins exact ties.
+// over top-level objects with the shrinking t_max; first object wins exact ties.  The record of
+// object i + 1 is requested before object i is tested, so the scalar-load latency overlaps the
+// arithmetic.
 // TRIS = false compiles the triangle test and the BVH traversal (and with it the stack) out, for
 // scenes made of spheres, planes and rectangles only.
 template<bool TRIS>
@@ -170,42 +184,49 @@ PTK_DEV bool closest_hit(const DevScene& sc, const V3& org, const V3& dir, doubl
     hit.t = INF;
     hit.obj = -1;
     hit.prim = 0;
+    hit.cls = 0;
     RayPrep rp{};
     if (TRIS) rp = prepare_ray(dir);
     const double dir_dot_org = dot(dir, org);
     double limit = t_max; // ray.t_max
-    // The object table is read through the constant address space: the index is wave-uniform, so the
-    // fields arrive by scalar loads and live in SGPRs instead of costing a vector load per lane.
-    const PTK_CONSTANT DevObject* objects = (const PTK_CONSTANT DevObject*) sc.objects;
-    for (int i = 0; i < sc.n_objects; i++) {
-        const PTK_CONSTANT DevObject& o = objects[i];
+    const PTK_CONSTANT DevShape* shapes = (const PTK_CONSTANT DevShape*) sc.shapes;
+    const int n = sc.n_objects;
+    DevShape o;
+    if (n > 0) load_shape(shapes, o);
+    // The first record must have arrived before the loop is entered: a load still pending at the
+    // loop header makes the compiler wait at the top of every iteration, which also waits for the
+    // prefetch of the next record issued there.
+    asm volatile("" : : "s"(o.type));
+    for (int i = 0; i < n; i++) {
+        DevShape next;
+        load_shape(shapes + (i + 1 < n ? i + 1 : i), next);
         double d = INF;
         int prim = 0;
         bool success = false;
         if (o.type == PTK_OBJ_SPHERE) { // :106-119
-            V3 c = v3(o.px, o.py, o.pz);
+            V3 c = v3(o.f[0], o.f[1], o.f[2]);
             double b = 2 * (dir_dot_org - dot(dir, c));
-            double cc = len2(c - org) - o.radius * o.radius;
+            double cc = len2(c - org) - o.f[3] * o.f[3];
             success = solve_quadratic(b, cc, d) && !(d > limit);
         }
         else if (o.type == PTK_OBJ_PLANE || o.type == PTK_OBJ_RECTANGLE) { // :185-211, :237-255
-            V3 n = v3(o.nx, o.ny, o.nz);
-            V3 shifted = org - v3(o.px, o.py, o.pz);
-            double ddn = -dot(dir, n);
+            V3 nrm = v3(o.f[3], o.f[4], o.f[5]);
+            V3 shifted = org - v3(o.f[0], o.f[1], o.f[2]);
+            double ddn = -dot(dir, nrm);
             if (!(fabs(ddn) < EPSILON)) {
-                d = dot(shifted, n) / ddn;
+                d = dot(shifted, nrm) / ddn;
                 success = !(d < EPSILON) && !(d > limit);
                 if (success && o.type == PTK_OBJ_RECTANGLE) {
-                    V3 a1 = v3(o.v1x, o.v1y, o.v1z), a2 = v3(o.v2x, o.v2y, o.v2z);
-                    if (fabs(dot(shifted, a1) + dot(dir, a1) * d) > o.L1 / 2.0 + EPSILON ||
-                        fabs(dot(shifted, a2) + dot(dir, a2) * d) > o.L2 / 2.0 + EPSILON)
+                    V3 a1 = v3(o.f[6], o.f[7], o.f[8]), a2 = v3(o.f[9], o.f[10], o.f[11]);
+                    if (fabs(dot(shifted, a1) + dot(dir, a1) * d) > o.f[12] / 2.0 + EPSILON ||
+                        fabs(dot(shifted, a2) + dot(dir, a2) * d) > o.f[13] / 2.0 + EPSILON)
                         success = false;
                 }
             }
         }
         else if (TRIS && o.type == PTK_OBJ_TRIANGLE) {
             success = triangle_hit(sc.tri_hot[o.first_tri], org, rp, limit, d);
-            prim = static_cast<int>(o.first_tri);
+            prim = o.first_tri;
         }
         else if (TRIS) { // mesh
             double tb = limit;
@@ -221,8 +242,10 @@ PTK_DEV bool closest_hit(const DevScene& sc, const V3& org, const V3& dir, doubl
             hit.t = d;
             hit.obj = i;
             hit.prim = prim;
+            hit.cls = o.cls;
             limit = d;
         }
+        o = next;
     }
     return hit.obj >= 0;
 }

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(TRIS ? 2 : PTK_TRACE_WAVE
                         t = h.t;
                         obj = h.obj;
                         prim = h.prim;
-                        cls = sc.materials[sc.objects[h.obj].material].type;
+                        cls = h.cls;
                     }
                     stu4(pool, PL_HIT, idx, static_cast<uint32_t>(__double2loint(t)), static_cast<uint32_t>(__double2hiint(t)),
                          static_cast<uint32_t>(obj), static_cast<uint32_t>(prim));

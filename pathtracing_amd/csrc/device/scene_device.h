@@ -61,6 +61,19 @@ struct DevObject {
     double mesh_light_area;  // mesh light: last cumulative area
 };
 
+// What the closest-hit loop reads per object: 128 bytes fetched by two scalar loads.
+//   sphere            f[0..2] centre, f[3] radius
+//   plane, rectangle  f[0..2] point, f[3..5] normal, f[6..8] axis 1, f[9..11] axis 2, f[12] L1, f[13] L2
+//   triangle, mesh    first_tri / bvh_root
+struct DevShape {
+    double f[14];
+    int32_t type;      // PTK_OBJ_*
+    int32_t cls;       // class (material type) of the object's material
+    int32_t first_tri; // triangle: its index; mesh: first triangle of its range
+    int32_t bvh_root;  // mesh: root node, -1 if empty
+};
+static_assert(sizeof(DevShape) == 128, "DevShape is read as two 64-byte scalar loads");
+
 struct TriHot { // vertices, fp64
     double p1[3], p2[3], p3[3];
 };
@@ -102,6 +115,7 @@ struct DevScene {
     double background[3];
     DevCamera cam;
     const DevObject* objects;
+    const DevShape* shapes;      // one per object, same order
     const DevMaterial* materials;
     const DevMedium* media;
     const DevMap* maps;

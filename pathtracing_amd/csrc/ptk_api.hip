@@ -685,6 +685,26 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     dev.n_maps = d->n_maps;
     dev.n_lights = static_cast<int32_t>(lights.size());
     dev.has_triangles = !tri_hot.empty();
+    std::vector<DevShape> shapes(objects.size());
+    for (size_t i = 0; i < objects.size(); i++) {
+        const DevObject& o = objects[i];
+        DevShape& sh = shapes[i];
+        std::memset(&sh, 0, sizeof(sh));
+        sh.type = o.type;
+        sh.cls = materials[static_cast<size_t>(o.material)].type;
+        sh.first_tri = static_cast<int32_t>(o.first_tri);
+        sh.bvh_root = o.bvh_root;
+        if (o.type == PTK_OBJ_SPHERE) {
+            sh.f[0] = o.px;
+            sh.f[1] = o.py;
+            sh.f[2] = o.pz;
+            sh.f[3] = o.radius;
+        }
+        else if (o.type == PTK_OBJ_PLANE || o.type == PTK_OBJ_RECTANGLE) {
+            const double v[14] = {o.px, o.py, o.pz, o.nx, o.ny, o.nz, o.v1x, o.v1y, o.v1z, o.v2x, o.v2y, o.v2z, o.L1, o.L2};
+            std::memcpy(sh.f, v, sizeof(v));
+        }
+    }
     dev.has_meshes = 0;
     dev.needs_uv = 0;
     for (const DevMaterial& m : materials)
@@ -705,6 +725,7 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
         if ((class_mask >> k) & 1u) s->classes.push_back(k);
 
     HIP_TRY(buf.upload(&dev.objects, objects));
+    HIP_TRY(buf.upload(&dev.shapes, shapes));
     HIP_TRY(buf.upload(&dev.materials, materials));
     HIP_TRY(buf.upload(&dev.media, media));
     HIP_TRY(buf.upload(&dev.maps, maps));
