@@ -141,7 +141,7 @@ def main():
     # of the timed region (event records drain the queue, so timing every step would slow the run).
     PROFILE_EVERY = 4
     profiled = {"steps": 0}
-    fam = {k: [0.0, 0, 0] for k in ("k_trace", "k_shade", "k_bin")}
+    fam = {k: [0.0, 0, 0] for k in ("k_bounce", "k_bin")}
 
     def step(i, timed=False):
         job = pt.make_job(0, n_pixels, spp, offset + i * spp, args.seed)
@@ -152,7 +152,7 @@ def main():
             pt.set_profiling(False)
             s1 = scene.stats()
             profiled["steps"] += 1
-            for k, f in (("k_trace", "trace"), ("k_shade", "shade"), ("k_bin", "bin")):
+            for k, f in (("k_bounce", "bounce"), ("k_bin", "bin")):
                 fam[k][0] += getattr(s1, f + "_ms") - getattr(s0, f + "_ms")
                 fam[k][1] += getattr(s1, f + "_bytes") - getattr(s0, f + "_bytes")
                 fam[k][2] += getattr(s1, f + "_launches") - getattr(s0, f + "_launches")

@@ -187,11 +187,11 @@ typedef struct PtkStats {
     uint64_t vertices;      /* surface + scatter vertices shaded */
     uint64_t bounce_launch_rounds;
     uint64_t algorithmic_bytes; /* path-state/queue bytes the kernels are specified to move */
-    /* Kernel families: trace = visibility marches + extension rays (one fused kernel), shade = the
-     * per-material kernels, bin = the class sort between them. */
-    double trace_ms, shade_ms, bin_ms, other_ms; /* device time per family, HIP events, while profiling is on */
-    uint64_t trace_launches, shade_launches, bin_launches;
-    uint64_t trace_bytes, shade_bytes, bin_bytes; /* algorithmic bytes per family */
+    /* Kernel families: bounce = the per-material kernels (shading, shadow ray and extension ray of
+     * one path vertex), bin = the class sort between bounces. */
+    double bounce_ms, bin_ms, other_ms, reserved_ms; /* device time per family, HIP events, while profiling is on */
+    uint64_t bounce_launches, bin_launches, reserved_launches;
+    uint64_t bounce_bytes, bin_bytes, reserved_bytes; /* algorithmic bytes per family */
 } PtkStats;
 
 /* Selects the GPU for this process (hipSetDevice) and creates the library's stream.

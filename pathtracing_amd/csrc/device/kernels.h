@@ -6,7 +6,7 @@
 
 namespace ptk {
 
-// number of blocks k_trace / k_bin_scatter use for n records (= entries of a block_counts row used)
+// number of blocks k_bin_count / k_bin_scatter use for n records (= entries of a block_counts row used)
 uint32_t bin_blocks(uint32_t n);
 
 // In every launcher `bound` is an upper bound of the number of records, used only to size the grid;
@@ -15,16 +15,14 @@ uint32_t bin_blocks(uint32_t n);
 // has to wait for a count before it queues the next bounce.
 void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathPool& pool, const SampleResults& res,
                      BinInfo* first_info);
-// pending connections + extension rays of the records of `pool`; counters: [0] march segments,
-// [1] extension rays, [2] connections, [3] records k_shade finished without a connection
-void launch_trace(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathPool& pool, const SampleResults& res, uint32_t bound,
-                  const BinInfo* previous, uint32_t* block_counts, uint32_t count_stride, unsigned long long* counters);
-// scan + scatter: class-sorted index list of the records of `pool`, summary in *info
+// count + scan + scatter: class-sorted index list of the records of `pool`, summary in *info
 void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_t bound, const BinInfo* previous, uint32_t* block_counts,
                 uint32_t count_stride, BinInfo* info, uint32_t* list_out);
-void launch_shade(hipStream_t s, int cls, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in,
-                  const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info,
-                  unsigned long long* counters);
+// one vertex of every path of class `cls`; statistics: STATISTICS_SLOTS x N_STATISTICS per-block slots
+void launch_bounce(hipStream_t s, int cls, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in,
+                   const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info,
+                   unsigned long long* statistics);
+void launch_sum_statistics(hipStream_t s, const unsigned long long* slots, unsigned long long* totals);
 void launch_accumulate(hipStream_t s, const BatchParams& b, const SampleResults& res, double* image, double* position, double* normal,
                        unsigned long long* pixel_counters);
 void launch_gather_samples(hipStream_t s, const BatchParams& b, const SampleResults& res, size_t pixel_base, double* color,

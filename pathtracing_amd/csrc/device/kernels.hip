@@ -1,26 +1,29 @@
 // Wavefront path-tracing kernels for gfx950.
 //
-//   k_generate     camera samples -> path records              (compute_pixel_color + Camera::make_ray)
-//   k_trace        per record: the visibility march of the connection the last shade left pending
-//                  (compute_visibility), then the free-flight distance and the closest hit of the
-//                  new ray (raytrace's loop head + find_closest_hit); records the class of the vertex
-//                  and leaves per-block class counts; paths that ended are flushed to the results
-//   k_bin_scan     exclusive scan of the per-block class counts
+//   k_generate     camera samples, their first closest hit -> path records
+//                  (compute_pixel_color + Camera::make_ray + the first loop head of raytrace)
+//   k_bin_count    per-block counts of the records of each class
+//   k_bin_scan     exclusive scan of those counts
 //   k_bin_scatter  writes the class-sorted index list           (stable: record order is preserved)
-//   k_shade<C>     one launch per material class over its segment of the list: emission with MIS,
-//                  next-event sampling up to the connection record, BRDF sampling, medium switch,
-//                  Russian roulette (raytrace's loop body); reads the record through the list and
-//                  writes the updated record to the other pool at the list position
+//   k_bounce<C>    one launch per material class over its segment of the list, one path vertex per
+//                  lane: emission with MIS, next-event sampling and the visibility march of that
+//                  connection (sample_light + compute_visibility), BRDF sampling, medium switch,
+//                  Russian roulette (raytrace's loop body), then the free-flight distance and the
+//                  closest hit of the new ray (the next loop head + find_closest_hit); reads the
+//                  record through the list and writes the updated record, with the class of its
+//                  next vertex, to the other pool at the list position
 //   k_accumulate   per-pixel sample means folded into the film  (compute_pixel_color's division and
 //                  increment_average)
 //
-// One lane owns one path.  Records move once per bounce, from one pool to the other, which keeps
-// the records in flight packed (coalesced 16-byte accesses whatever fraction of the batch is still
-// alive) at no extra traffic: a shade kernel rewrites most of the record anyway.  Sorting by class
-// uses block-local ballots and a scan instead of global atomics: with one atomic per wave on a
-// shared counter the kernels ran at the rate of that one cache line (about 100 atomics per
-// microsecond) instead of at the rate of the arithmetic.  All arithmetic is fp64, as in the
-// reference; MFMA has no role here (divergent scalar-per-lane work, no dense contraction).
+// One lane owns one path.  A bounce is one pass over the records: shading, the shadow ray and the
+// extension ray happen while the record is in registers, so a vertex costs one read and one write
+// of a 160-byte record.  Records move once per bounce, from one pool to the other, which keeps the
+// records in flight packed (coalesced 16-byte accesses whatever fraction of the batch is still
+// alive).  Sorting by class uses block-local ballots and a scan instead of global atomics: with one
+// atomic per wave on a shared counter the kernels ran at the rate of that one cache line (about
+// 100 atomics per microsecond) instead of at the rate of the arithmetic; the statistics counters
+// are per-block slots for the same reason.  All arithmetic is fp64, as in the reference; MFMA has
+// no role here (divergent scalar-per-lane work, no dense contraction).
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -31,11 +34,8 @@ namespace ptk {
 constexpr int BLOCK = 256;
 // Register budgets: the kernels are compiled for a fixed number of waves per SIMD (512 registers
 // per lane and SIMD are shared by the resident waves).
-#ifndef PTK_TRACE_WAVES
-#define PTK_TRACE_WAVES 4
-#endif
-#ifndef PTK_SHADE_WAVES
-#define PTK_SHADE_WAVES 3
+#ifndef PTK_BOUNCE_WAVES
+#define PTK_BOUNCE_WAVES 2
 #endif
 #define PTK_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 static_assert(BLOCK == BIN_BLOCK, "k_extend and the bin kernels share their block geometry");
@@ -113,8 +113,6 @@ PTK_DEV uint4 ldu4(const PathPool& p, int plane, uint32_t i) {
 PTK_DEV void stu4(const PathPool& p, int plane, uint32_t i, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     *reinterpret_cast<uint4*>(plane_ptr(p, plane) + i * 16u) = make_uint4(a, b, c, d);
 }
-PTK_DEV double key_as_double(uint64_t k) { return __longlong_as_double(static_cast<long long>(k)); }
-PTK_DEV uint64_t double_as_key(double d) { return static_cast<uint64_t>(__double_as_longlong(d)); }
 
 // The path ended: its radiance goes to the per-sample results.
 PTK_DEV void flush_color(const SampleResults& res, uint32_t sid, double r, double g, double bl) {
@@ -126,8 +124,68 @@ PTK_DEV double2* surface_plane(const SampleResults& res, int plane) {
     return reinterpret_cast<double2*>(res.surface + static_cast<uint64_t>(plane) * res.plane_doubles);
 }
 
+// Statistics without atomics on shared lines: every block adds its totals to its own slot.
+// values: [0] visibility-march segments, [1] extension rays, [2] connections marched,
+// [3] records written for the next bounce.
+PTK_DEV void add_block_statistics(unsigned long long* slots, uint32_t (*wave_sums)[N_STATISTICS], uint32_t* mine) {
+#pragma unroll
+    for (int k = 0; k < N_STATISTICS; k++)
+        for (int off = 32; off > 0; off >>= 1) mine[k] += __shfl_down(mine[k], off);
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < N_STATISTICS; k++) wave_sums[threadIdx.x >> 6][k] = mine[k];
+    __syncthreads();
+    if (threadIdx.x < N_STATISTICS) {
+        uint32_t total = 0;
+        for (int w = 0; w < BLOCK / 64; w++) total += wave_sums[w][threadIdx.x];
+        if (total) slots[static_cast<size_t>(blockIdx.x % STATISTICS_SLOTS) * N_STATISTICS + threadIdx.x] += total;
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
+// Loop head of raytrace (app/pathtracer.cpp:53-67) for a new ray: free-flight distance in a
+// scattering medium, closest hit.  cls < 0: the ray left the scene.
+struct Vertex {
+    double t;
+    int obj, prim, cls;
+};
+
+template<bool TRIS>
+PTK_DEV Vertex next_vertex(const DevScene& sc, const BatchParams& b, const V3& org, const V3& dir, uint32_t medium, uint32_t sid,
+                           uint32_t ctr, TraversalStack& st) {
+    if (medium == MEDIUM_NONE) medium = static_cast<uint32_t>(sc.background_medium);
+    const DevMedium& med = sc.media[medium];
+    double scatter_distance = INF;
+    if (med.type == PTK_MEDIUM_HOMOGENEOUS_SCATTERING) { // HomogenousScatteringMedium::sample_distance
+        uint32_t pixel, sample;
+        sample_coordinates(b, sid, pixel, sample);
+        Rng rng{rng_key(b.seed, pixel, sample), ctr};
+        int channel = rng.integer(0, 3);
+        double ext = med.extinction[channel];
+        if (ext != 0) scatter_distance = -log(rng.u01()) / ext;
+    }
+    HitInfo h;
+    const bool found = closest_hit<TRIS>(sc, org, dir, scatter_distance, h, st);
+    Vertex v;
+    if (found) {
+        v.t = h.t;
+        v.obj = h.obj;
+        v.prim = h.prim;
+        v.cls = h.cls;
+    }
+    else { // a scatter event before any surface, or nothing at all
+        v.t = scatter_distance;
+        v.obj = -1;
+        v.prim = 0;
+        v.cls = scatter_distance == INF ? -1 : CLASS_SCATTER;
+    }
+    return v;
+}
+
+// -------------------------------------------------------------------------------------------------
+template<bool TRIS>
 __global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, PathPool pool, SampleResults res, BinInfo* first_info) {
+    __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1];
+    TraversalStack st = make_stack(lds_stack);
     if (blockIdx.x == 0 && threadIdx.x == 0) first_info->total = b.n_paths; // records in the first pool
     for (uint32_t sid = blockIdx.x * BLOCK + threadIdx.x; sid < b.n_paths; sid += gridDim.x * BLOCK) {
         uint32_t pixel, sample;
@@ -135,6 +193,16 @@ __global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, 
         Rng rng{rng_key(b.seed, pixel, sample), 0};
         V3 org, dir;
         camera_ray(sc, pixel, rng, org, dir);
+        surface_plane(res, 0)[sid] = make_double2(0.0, 0.0);
+        surface_plane(res, 1)[sid] = make_double2(0.0, 0.0);
+        surface_plane(res, 2)[sid] = make_double2(0.0, 0.0);
+        const uint32_t medium = static_cast<uint32_t>(sc.background_medium) & 0xFFFFu;
+        const Vertex v = next_vertex<TRIS>(sc, b, org, dir, medium, sid, rng.ctr, st);
+        if (v.cls < 0) { // color = throughput (1) * background_color
+            flush_color(res, sid, sc.background[0], sc.background[1], sc.background[2]);
+            pool.cls[sid] = CLASS_DONE;
+            continue;
+        }
         st2(pool, PL_RAY0, sid, org.x, org.y);
         st2(pool, PL_RAY1, sid, org.z, dir.x);
         st2(pool, PL_RAY2, sid, dir.y, dir.z);
@@ -142,155 +210,42 @@ __global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, 
         st2(pool, PL_THR1, sid, 1.0, 0.0);
         st2(pool, PL_SAV0, sid, 0.0, 0.0);
         st2(pool, PL_SAV1, sid, 0.0, 0.0);
-        st2(pool, PL_COL0, sid, 0.0, 0.0);
-        st2(pool, PL_COL1, sid, 0.0, 0.0);
-        stu4(pool, PL_IDS, sid, 0u | (RAY_TRANSMITTED << TYPE_SHIFT) | (static_cast<uint32_t>(sc.background_medium) << 16), sid,
-             rng.ctr, 0u);
-        pool.cls[sid] = 0;
-        surface_plane(res, 0)[sid] = make_double2(0.0, 0.0);
-        surface_plane(res, 1)[sid] = make_double2(0.0, 0.0);
-        surface_plane(res, 2)[sid] = make_double2(0.0, 0.0);
+        st2(pool, PL_COL, sid, 0.0, 0.0);
+        *reinterpret_cast<uint4*>(plane_ptr(pool, PL_HIT) + sid * 16u) =
+            make_uint4(static_cast<uint32_t>(__double2loint(v.t)), static_cast<uint32_t>(__double2hiint(v.t)),
+                       0u | (RAY_TRANSMITTED << TYPE_SHIFT) | (medium << 16), sid);
+        stu4(pool, PL_IDS, sid, rng.ctr, static_cast<uint32_t>(v.obj), static_cast<uint32_t>(v.prim), 0u);
+        pool.cls[sid] = static_cast<uint8_t>(v.cls);
     }
 }
 
-// -------------------------------------------------------------------------------------------------
-// For every record of the current pool: finish the connection the last shade left pending
-// (compute_visibility, src/objects.cpp:470-513, and the acceptance test of sample_light :558), then
-// run the loop head of raytrace (app/pathtracer.cpp:53-67) for the new ray: free-flight distance,
-// closest hit, miss handling.  Block b owns records [b * BIN_CHUNK, (b + 1) * BIN_CHUNK) and leaves
-// its per-class counts in block_counts[class * count_stride + b].
-// counters: [0] visibility-march segments, [1] extension rays, [2] connections marched.
-// TRIS: the scene has triangles or meshes; UV: some material reads a map larger than 1x1 (texture
-// coordinates are needed).  Scenes without them get kernels without that code and its registers.
-template<bool TRIS, bool UV>
-__global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(TRIS ? 2 : PTK_TRACE_WAVES) void k_trace(DevScene sc, BatchParams b, PathPool pool, SampleResults res, const BinInfo* previous,
-                                                 uint32_t* block_counts, uint32_t count_stride, unsigned long long* counters) {
-    const uint32_t n = previous->total; // records the previous bounce's shade kernels wrote
+// Per-block class counts of the records of `pool`: block b owns records [b * BIN_CHUNK,
+// (b + 1) * BIN_CHUNK) and leaves its counts in block_counts[class * count_stride + b].
+__global__ __launch_bounds__(BLOCK) void k_bin_count(PathPool pool, const BinInfo* previous, uint32_t* block_counts, uint32_t count_stride,
+                                                     uint32_t class_mask) {
+    const uint32_t n = previous->total;
     if (blockIdx.x * BIN_CHUNK >= n) return;
-    __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1];
     __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
-    __shared__ uint32_t wave_rays[BLOCK / 64][3];
-    TraversalStack st = make_stack(lds_stack);
     uint32_t my_counts[N_CLASSES];
 #pragma unroll
     for (int c = 0; c < N_CLASSES; c++) my_counts[c] = 0;
-    uint32_t segments = 0, extensions = 0, connections = 0; // per lane
+#pragma unroll
     for (int r = 0; r < BIN_ROUNDS; r++) {
         const uint32_t idx = blockIdx.x * BIN_CHUNK + r * BLOCK + threadIdx.x;
-        int cls = -1;
-        const uint8_t mark = idx < n ? pool.cls[idx] : CLASS_DONE;
-        if (mark != CLASS_DONE) {
-            const uint4 ids = ldu4(pool, PL_IDS, idx);
-            const double2 r0 = ld2(pool, PL_RAY0, idx), r1 = ld2(pool, PL_RAY1, idx);
-            const V3 org = v3(r0.x, r0.y, r1.x);
-            const uint32_t sid = ids.y;
-            double2 c0 = make_double2(0.0, 0.0), c1 = c0;
-            bool color_loaded = false, color_changed = false;
-            if (ids.w & SHADOW_VALID) {
-                c0 = ld2(pool, PL_COL0, idx);
-                c1 = ld2(pool, PL_COL1, idx);
-                color_loaded = true;
-                const double2 s0 = ld2(pool, PL_SH0, idx), s1 = ld2(pool, PL_SH1, idx), s2 = ld2(pool, PL_SH2, idx);
-                const double2 v1 = ld2(pool, PL_SAV1, idx);
-                Rng rng{double_as_key(c1.y), 0};
-                connections++;
-                V3 visible = march_to_light<TRIS, UV>(sc, org, v3(s0.x, s0.y, s1.x), static_cast<int>((ids.w >> 16) & 0x7FFFu),
-                                                    static_cast<int>(ids.w & 0xFFFFu), s1.y, rng, st, segments);
-                if (visible.x != 0 || visible.y != 0 || visible.z != 0) {
-                    c0.x += s2.x * visible.x;
-                    c0.y += s2.y * visible.y;
-                    c1.x += v1.y * visible.z;
-                    color_changed = true;
-                }
-            }
-            if (mark == CLASS_DEAD) {
-                if (!color_loaded) {
-                    c0 = ld2(pool, PL_COL0, idx);
-                    c1 = ld2(pool, PL_COL1, idx);
-                }
-                flush_color(res, sid, c0.x, c0.y, c1.x);
-            }
-            else {
-                const double2 r2 = ld2(pool, PL_RAY2, idx);
-                const V3 dir = v3(r1.y, r2.x, r2.y);
-                uint32_t medium = ids.x >> 16;
-                if (medium == MEDIUM_NONE) medium = static_cast<uint32_t>(sc.background_medium);
-                const DevMedium& med = sc.media[medium];
-                double scatter_distance = INF;
-                if (med.type == PTK_MEDIUM_HOMOGENEOUS_SCATTERING) { // HomogenousScatteringMedium::sample_distance
-                    uint32_t pixel, sample;
-                    sample_coordinates(b, sid, pixel, sample);
-                    Rng rng{rng_key(b.seed, pixel, sample), ids.z};
-                    int channel = rng.integer(0, 3);
-                    double ext = med.extinction[channel];
-                    if (ext != 0) scatter_distance = -log(rng.u01()) / ext;
-                }
-                HitInfo h;
-                bool found = closest_hit<TRIS>(sc, org, dir, scatter_distance, h, st);
-                extensions++;
-                if (!found && scatter_distance == INF) {
-                    // color += throughput * background_color; the path ends
-                    if (!color_loaded) {
-                        c0 = ld2(pool, PL_COL0, idx);
-                        c1 = ld2(pool, PL_COL1, idx);
-                    }
-                    if (!sc.background_is_black) {
-                        const double2 t0 = ld2(pool, PL_THR0, idx), t1 = ld2(pool, PL_THR1, idx);
-                        c0.x += t0.x * sc.background[0];
-                        c0.y += t0.y * sc.background[1];
-                        c1.x += t1.x * sc.background[2];
-                    }
-                    flush_color(res, sid, c0.x, c0.y, c1.x);
-                    pool.cls[idx] = CLASS_DONE;
-                }
-                else {
-                    int obj = -1, prim = 0;
-                    double t = scatter_distance;
-                    cls = CLASS_SCATTER; // scatter event before any surface
-                    if (found) {
-                        t = h.t;
-                        obj = h.obj;
-                        prim = h.prim;
-                        cls = h.cls;
-                    }
-                    stu4(pool, PL_HIT, idx, static_cast<uint32_t>(__double2loint(t)), static_cast<uint32_t>(__double2hiint(t)),
-                         static_cast<uint32_t>(obj), static_cast<uint32_t>(prim));
-                    pool.cls[idx] = static_cast<uint8_t>(cls);
-                    if (color_changed) {
-                        st2(pool, PL_COL0, idx, c0.x, c0.y);
-                        st2(pool, PL_COL1, idx, c1.x, c1.y);
-                    }
-                }
-            }
-        }
+        const int cls = idx < n ? pool.cls[idx] : 0xFF;
 #pragma unroll
         for (int c = 0; c < N_CLASSES; c++)
-            if ((sc.class_mask >> c) & 1u) my_counts[c] += static_cast<uint32_t>(__popcll(__ballot(cls == c)));
+            if ((class_mask >> c) & 1u) my_counts[c] += static_cast<uint32_t>(__popcll(__ballot(cls == c)));
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        segments += __shfl_down(segments, off);
-        extensions += __shfl_down(extensions, off);
-        connections += __shfl_down(connections, off);
-    }
-    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int c = 0; c < N_CLASSES; c++) wave_counts[wave][c] = my_counts[c];
-        wave_rays[wave][0] = segments;
-        wave_rays[wave][1] = extensions;
-        wave_rays[wave][2] = connections;
+        for (int c = 0; c < N_CLASSES; c++) wave_counts[threadIdx.x >> 6][c] = my_counts[c];
     }
     __syncthreads();
     if (threadIdx.x < N_CLASSES) {
         uint32_t total = 0;
         for (int w = 0; w < BLOCK / 64; w++) total += wave_counts[w][threadIdx.x];
         block_counts[threadIdx.x * count_stride + blockIdx.x] = total;
-    }
-    if (threadIdx.x >= 64 && threadIdx.x < 67) { // statistics: one atomic per block and counter
-        const int k = threadIdx.x - 64;
-        uint32_t total = 0;
-        for (int w = 0; w < BLOCK / 64; w++) total += wave_rays[w][k];
-        if (total) atomicAdd(counters + k, static_cast<unsigned long long>(total));
     }
 }
 
@@ -404,31 +359,39 @@ __global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathPool pool, const BinI
 }
 
 // -------------------------------------------------------------------------------------------------
-// Loop body of raytrace (app/pathtracer.cpp:69-171) for the vertices of one class.  Reads record
+// One vertex of every path whose current vertex has class CLS: the loop body of raytrace
+// (app/pathtracer.cpp:69-171) followed by the head of its next iteration (:53-67).  Reads record
 // list[first + j] of `in`, writes record first + j of `out`.
-// counters[3]: records that needed nothing further (path ended, no connection pending).
+// TRIS: the scene has triangles or meshes; UV: some material reads a map larger than 1x1 (texture
+// coordinates are needed).  Scenes without them get kernels without that code and its registers.
 template<int CLS, bool TRIS, bool UV>
-__global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_SHADE_WAVES) void k_shade(DevScene sc, BatchParams b, PathPool in, PathPool out, SampleResults res,
-                                                 const uint32_t* list, const BinInfo* info, unsigned long long* counters) {
+__global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_bounce(DevScene sc, BatchParams b, PathPool in, PathPool out,
+                                                                                      SampleResults res, const uint32_t* list,
+                                                                                      const BinInfo* info, unsigned long long* statistics) {
+    __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1];
+    __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
+    TraversalStack st = make_stack(lds_stack);
     const uint32_t n = info->count[CLS];
     const uint32_t first = info->start[CLS];
-    uint32_t finished = 0;
+    uint32_t stat[N_STATISTICS] = {0, 0, 0, 0};
+    if (blockIdx.x * BLOCK >= n) return;
     for (uint32_t qi = blockIdx.x * BLOCK + threadIdx.x; qi < n; qi += gridDim.x * BLOCK) {
         const uint32_t dst = first + qi;
         const uint32_t src = list[dst];
         const double2 r0 = ld2(in, PL_RAY0, src), r1 = ld2(in, PL_RAY1, src), r2 = ld2(in, PL_RAY2, src);
         const double2 t0 = ld2(in, PL_THR0, src), t1 = ld2(in, PL_THR1, src);
         const double2 v0 = ld2(in, PL_SAV0, src), v1 = ld2(in, PL_SAV1, src);
-        double2 c0 = ld2(in, PL_COL0, src), c1 = ld2(in, PL_COL1, src);
-        const uint4 ids = ldu4(in, PL_IDS, src);
+        const double2 cc = ld2(in, PL_COL, src);
         const uint4 hit = ldu4(in, PL_HIT, src);
+        const uint4 ids = ldu4(in, PL_IDS, src);
         V3 org = v3(r0.x, r0.y, r1.x);
         V3 dir = v3(r1.y, r2.x, r2.y);
         V3 thr = v3(t0.x, t0.y, t1.x);
         V3 saved = v3(v0.x, v0.y, v1.x);
+        V3 color = v3(v1.y, cc.x, cc.y);
         double scatter_pdf = t1.y;
-        const uint32_t flags = ids.x;
-        const uint32_t sid = ids.y;
+        const uint32_t flags = hit.z;
+        const uint32_t sid = hit.w;
         const uint32_t depth = flags & DEPTH_MASK;
         uint32_t ray_type = (flags >> TYPE_SHIFT) & 3u;
         bool has_hit = (flags & FLAG_HAS_HIT) != 0;
@@ -437,10 +400,10 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_SHADE_WAVES) void k_s
         const DevMedium& med = sc.media[medium];
         uint32_t pixel, sample;
         sample_coordinates(b, sid, pixel, sample);
-        Rng rng{rng_key(b.seed, pixel, sample), ids.z};
+        Rng rng{rng_key(b.seed, pixel, sample), ids.x};
         if (med.type == PTK_MEDIUM_HOMOGENEOUS_SCATTERING) {
-            // the numbers k_trace drew for the free-flight distance: the channel, and the
-            // distance only when that channel attenuates (src/medium.cpp:45-51)
+            // the numbers drawn for the free-flight distance when this vertex was found: the
+            // channel, and the distance only when that channel attenuates (src/medium.cpp:45-51)
             int channel = rng.integer(0, 3);
             if (med.extinction[channel] != 0) rng.ctr++;
         }
@@ -448,17 +411,15 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_SHADE_WAVES) void k_s
         const V3 point = org + dir * t;
         int next_medium = static_cast<int>(medium);
         V3 n_dir;
-        uint32_t sh_info = 0;
+        bool connect = false;
+        int light_index = 0;
         V3 sh_dir = v3(0.0), sh_contrib = v3(0.0);
         double sh_dist = 0;
         uint64_t sh_key = 0;
 
         if (CLS == CLASS_SCATTER) {
             // :71-93
-            V3 emission = medium_emission(med) * thr;
-            c0.x += emission.x;
-            c0.y += emission.y;
-            c1.x += emission.z;
+            color = color + medium_emission(med) * thr;
             thr = thr * medium_sample_weight(med, t, true);
             n_dir = sample_spherical(rng);
             if (sc.nee) {
@@ -470,7 +431,8 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_SHADE_WAVES) void k_s
                     sh_dist = ls.distance;
                     sh_key = rng_fork(rng.key, rng.ctr);
                     rng.ctr++;
-                    sh_info = SHADOW_VALID | static_cast<uint32_t>(ls.light_index) | (medium << 16);
+                    light_index = ls.light_index;
+                    connect = true;
                 }
                 ray_type = RAY_DIFFUSE;
                 scatter_pdf = PHASE_ISOTROPIC;
@@ -480,8 +442,8 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_SHADE_WAVES) void k_s
         else {
             // :94-155
             thr = thr * medium_sample_weight(med, t, false);
-            const int obj = static_cast<int>(hit.z);
-            const int prim = static_cast<int>(hit.w);
+            const int obj = static_cast<int>(ids.y);
+            const int prim = static_cast<int>(ids.z);
             const DevObject& o = sc.objects[obj];
             const DevMaterial& m = sc.materials[o.material];
             Surface s;
@@ -507,10 +469,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_SHADE_WAVES) void k_s
                 double weight = 1;
                 if (sc.nee && depth != 0 && !is_specular)
                     weight = mis_weight(scatter_pdf, object_light_pdf<TRIS>(sc, o, point, saved, prim));
-                V3 add = material_emittance(sc, m, s.use_uv, s.u, s.v) * weight * thr;
-                c0.x += add.x;
-                c0.y += add.y;
-                c1.x += add.z;
+                color = color + material_emittance(sc, m, s.use_uv, s.u, s.v) * weight * thr;
             }
             if (sc.nee) { // sample_light up to the march (src/objects.cpp:515-551, 562-578)
                 LightSample ls;
@@ -528,7 +487,8 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_SHADE_WAVES) void k_s
                             sh_dir = ls.direction;
                             sh_dist = ls.distance;
                             sh_key = key;
-                            sh_info = SHADOW_VALID | static_cast<uint32_t>(ls.light_index) | (medium << 16);
+                            light_index = ls.light_index;
+                            connect = true;
                         }
                     }
                 }
@@ -558,38 +518,61 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_SHADE_WAVES) void k_s
         }
         const bool alive = allow && static_cast<int>(depth) + 1 <= sc.max_depth;
 
-        if (!alive && !(sh_info & SHADOW_VALID)) { // nothing left to do for this path
-            flush_color(res, sid, c0.x, c0.y, c1.x);
+        // the connection: compute_visibility (src/objects.cpp:470-513) and the acceptance test of
+        // sample_light (:558), on its own forked random-number stream
+        if (connect) {
+            Rng march_rng{sh_key, 0};
+            stat[2]++;
+            V3 visible = march_to_light<TRIS, UV>(sc, point, sh_dir, static_cast<int>(medium), light_index, sh_dist, march_rng, st, stat[0]);
+            color = color + sh_contrib * visible;
+        }
+
+        // the head of the next loop iteration: where does the new ray end
+        Vertex nv;
+        nv.cls = -1;
+        const uint32_t medium_bits = next_medium < 0 ? MEDIUM_NONE : static_cast<uint32_t>(next_medium);
+        if (alive) {
+            stat[1]++;
+            nv = next_vertex<TRIS>(sc, b, point, n_dir, medium_bits, sid, rng.ctr, st);
+            if (nv.cls < 0 && !sc.background_is_black) color = color + thr * v3(sc.background);
+        }
+        if (nv.cls < 0) { // the path ended here
+            flush_color(res, sid, color.x, color.y, color.z);
             out.cls[dst] = CLASS_DONE;
-            finished++;
             continue;
         }
-        // the new ray's origin is also the origin of the pending connection
+        stat[3]++;
         st2(out, PL_RAY0, dst, point.x, point.y);
         st2(out, PL_RAY1, dst, point.z, n_dir.x);
-        st2(out, PL_SAV1, dst, saved.z, sh_contrib.z);
-        st2(out, PL_COL0, dst, c0.x, c0.y);
-        st2(out, PL_COL1, dst, c1.x, key_as_double(sh_key));
-        stu4(out, PL_IDS, dst,
-             (depth + 1) | (ray_type << TYPE_SHIFT) | (has_hit ? FLAG_HAS_HIT : 0u) |
-                 ((next_medium < 0 ? MEDIUM_NONE : static_cast<uint32_t>(next_medium)) << 16),
-             sid, rng.ctr, sh_info);
-        if (sh_info & SHADOW_VALID) {
-            st2(out, PL_SH0, dst, sh_dir.x, sh_dir.y);
-            st2(out, PL_SH1, dst, sh_dir.z, sh_dist);
-            st2(out, PL_SH2, dst, sh_contrib.x, sh_contrib.y);
-        }
-        if (alive) {
-            st2(out, PL_RAY2, dst, n_dir.y, n_dir.z);
-            st2(out, PL_THR0, dst, thr.x, thr.y);
-            st2(out, PL_THR1, dst, thr.z, scatter_pdf);
-            st2(out, PL_SAV0, dst, saved.x, saved.y);
-        }
-        out.cls[dst] = alive ? 0 : CLASS_DEAD;
+        st2(out, PL_RAY2, dst, n_dir.y, n_dir.z);
+        st2(out, PL_THR0, dst, thr.x, thr.y);
+        st2(out, PL_THR1, dst, thr.z, scatter_pdf);
+        st2(out, PL_SAV0, dst, saved.x, saved.y);
+        st2(out, PL_SAV1, dst, saved.z, color.x);
+        st2(out, PL_COL, dst, color.y, color.z);
+        stu4(out, PL_HIT, dst, static_cast<uint32_t>(__double2loint(nv.t)), static_cast<uint32_t>(__double2hiint(nv.t)),
+             (depth + 1) | (ray_type << TYPE_SHIFT) | (has_hit ? FLAG_HAS_HIT : 0u) | (medium_bits << 16), sid);
+        stu4(out, PL_IDS, dst, rng.ctr, static_cast<uint32_t>(nv.obj), static_cast<uint32_t>(nv.prim), 0u);
+        out.cls[dst] = static_cast<uint8_t>(nv.cls);
     }
-    // statistics: one atomic per wave that finished anything (rare: most ended paths still connect)
-    for (int off = 32; off > 0; off >>= 1) finished += __shfl_down(finished, off);
-    if ((threadIdx.x & 63) == 0 && finished) atomicAdd(counters + 3, static_cast<unsigned long long>(finished));
+    add_block_statistics(statistics, wave_sums, stat);
+}
+
+// Sums the per-block statistics slots into totals[N_STATISTICS]; one block.
+__global__ __launch_bounds__(BLOCK) void k_sum_statistics(const unsigned long long* slots, unsigned long long* totals) {
+    __shared__ unsigned long long partial[BLOCK];
+    for (int k = 0; k < N_STATISTICS; k++) {
+        unsigned long long sum = 0;
+        for (int s = threadIdx.x; s < STATISTICS_SLOTS; s += BLOCK) sum += slots[static_cast<size_t>(s) * N_STATISTICS + k];
+        partial[threadIdx.x] = sum;
+        __syncthreads();
+        for (int off = BLOCK / 2; off > 0; off >>= 1) {
+            if (threadIdx.x < off) partial[threadIdx.x] += partial[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) totals[k] = partial[0];
+        __syncthreads();
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -702,63 +685,54 @@ uint32_t bin_blocks(uint32_t n) {
 
 void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathPool& pool, const SampleResults& res,
                      BinInfo* first_info) {
-    hipLaunchKernelGGL(k_generate, dim3(grid_for(b.n_paths, 4096)), dim3(BLOCK), 0, s, sc, b, pool, res, first_info);
-}
-
-void launch_trace(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathPool& pool, const SampleResults& res, uint32_t bound,
-                  const BinInfo* previous, uint32_t* block_counts, uint32_t count_stride, unsigned long long* counters) {
-    const dim3 grid(bin_blocks(bound)), block(BLOCK);
-#define PTK_LAUNCH_TRACE(T, U) \
-    hipLaunchKernelGGL((k_trace<T, U>), grid, block, 0, s, sc, b, pool, res, previous, block_counts, count_stride, counters)
-    if (sc.has_triangles) {
-        if (sc.needs_uv) PTK_LAUNCH_TRACE(true, true);
-        else PTK_LAUNCH_TRACE(true, false);
-    }
-    else {
-        if (sc.needs_uv) PTK_LAUNCH_TRACE(false, true);
-        else PTK_LAUNCH_TRACE(false, false);
-    }
-#undef PTK_LAUNCH_TRACE
+    const dim3 grid(grid_for(b.n_paths, 8192)), block(BLOCK);
+    if (sc.has_triangles) hipLaunchKernelGGL(k_generate<true>, grid, block, 0, s, sc, b, pool, res, first_info);
+    else hipLaunchKernelGGL(k_generate<false>, grid, block, 0, s, sc, b, pool, res, first_info);
 }
 
 void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_t bound, const BinInfo* previous, uint32_t* block_counts,
                 uint32_t count_stride, BinInfo* info, uint32_t* list_out) {
+    const dim3 grid(bin_blocks(bound)), block(BLOCK);
+    hipLaunchKernelGGL(k_bin_count, grid, block, 0, s, pool, previous, block_counts, count_stride, sc.class_mask);
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, block_counts, count_stride, sc.class_mask, previous, info);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(bin_blocks(bound)), dim3(BLOCK), 0, s, pool, previous, block_counts, count_stride,
-                       sc.class_mask, list_out);
+    hipLaunchKernelGGL(k_bin_scatter, grid, block, 0, s, pool, previous, block_counts, count_stride, sc.class_mask, list_out);
 }
 
 template<int CLS>
-static void launch_shade_t(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in,
-                           const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info,
-                           unsigned long long* counters) {
-    const dim3 grid(grid_for(bound, 8192)), block(BLOCK);
-#define PTK_LAUNCH_SHADE(T, U) hipLaunchKernelGGL((k_shade<CLS, T, U>), grid, block, 0, s, sc, b, in, out, res, list, info, counters)
+static void launch_bounce_t(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in,
+                            const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info,
+                            unsigned long long* statistics) {
+    const dim3 grid(grid_for(bound, STATISTICS_SLOTS)), block(BLOCK);
+#define PTK_LAUNCH_BOUNCE(T, U) hipLaunchKernelGGL((k_bounce<CLS, T, U>), grid, block, 0, s, sc, b, in, out, res, list, info, statistics)
     if (sc.has_triangles) {
-        if (sc.needs_uv) PTK_LAUNCH_SHADE(true, true);
-        else PTK_LAUNCH_SHADE(true, false);
+        if (sc.needs_uv) PTK_LAUNCH_BOUNCE(true, true);
+        else PTK_LAUNCH_BOUNCE(true, false);
     }
     else {
-        if (sc.needs_uv) PTK_LAUNCH_SHADE(false, true);
-        else PTK_LAUNCH_SHADE(false, false);
+        if (sc.needs_uv) PTK_LAUNCH_BOUNCE(false, true);
+        else PTK_LAUNCH_BOUNCE(false, false);
     }
-#undef PTK_LAUNCH_SHADE
+#undef PTK_LAUNCH_BOUNCE
 }
 
-void launch_shade(hipStream_t s, int cls, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in,
-                  const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info,
-                  unsigned long long* counters) {
+void launch_bounce(hipStream_t s, int cls, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in,
+                   const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info,
+                   unsigned long long* statistics) {
     switch (cls) {
-        case 0: launch_shade_t<0>(s, bound, sc, b, in, out, res, list, info, counters); break;
-        case 1: launch_shade_t<1>(s, bound, sc, b, in, out, res, list, info, counters); break;
-        case 2: launch_shade_t<2>(s, bound, sc, b, in, out, res, list, info, counters); break;
-        case 3: launch_shade_t<3>(s, bound, sc, b, in, out, res, list, info, counters); break;
-        case 4: launch_shade_t<4>(s, bound, sc, b, in, out, res, list, info, counters); break;
-        case 5: launch_shade_t<5>(s, bound, sc, b, in, out, res, list, info, counters); break;
-        case 6: launch_shade_t<6>(s, bound, sc, b, in, out, res, list, info, counters); break;
-        case 7: launch_shade_t<7>(s, bound, sc, b, in, out, res, list, info, counters); break;
+        case 0: launch_bounce_t<0>(s, bound, sc, b, in, out, res, list, info, statistics); break;
+        case 1: launch_bounce_t<1>(s, bound, sc, b, in, out, res, list, info, statistics); break;
+        case 2: launch_bounce_t<2>(s, bound, sc, b, in, out, res, list, info, statistics); break;
+        case 3: launch_bounce_t<3>(s, bound, sc, b, in, out, res, list, info, statistics); break;
+        case 4: launch_bounce_t<4>(s, bound, sc, b, in, out, res, list, info, statistics); break;
+        case 5: launch_bounce_t<5>(s, bound, sc, b, in, out, res, list, info, statistics); break;
+        case 6: launch_bounce_t<6>(s, bound, sc, b, in, out, res, list, info, statistics); break;
+        case 7: launch_bounce_t<7>(s, bound, sc, b, in, out, res, list, info, statistics); break;
         default: break;
     }
+}
+
+void launch_sum_statistics(hipStream_t s, const unsigned long long* slots, unsigned long long* totals) {
+    hipLaunchKernelGGL(k_sum_statistics, dim3(1), dim3(BLOCK), 0, s, slots, totals);
 }
 
 void launch_accumulate(hipStream_t s, const BatchParams& b, const SampleResults& res, double* image, double* position, double* normal,

@@ -129,12 +129,15 @@ struct DevScene {
     uint32_t class_mask;                 // material classes present in the scene (+ scatter bit)
 };
 
+constexpr int N_STATISTICS = 4;         // values per statistics slot (see kernels.hip)
+constexpr int STATISTICS_SLOTS = 8192; // per-block slots = the largest k_bounce grid
+
 // Path records live in two pools used ping-pong.  A pool is a set of planes of 16-byte elements
 // (plane p of record i at base + p * plane_bytes + 16 * i), so a wave reads or writes 1 KiB of
 // consecutive memory per instruction and every record is reached from one base pointer plus a
-// 32-bit offset.  Each bounce's shade kernels read the records of their class through the sorted
-// index list and write the updated records to the other pool at the list position, so the records
-// of the paths still in flight are always packed at the front of the current pool.
+// 32-bit offset.  Each bounce's kernels read the records of their class through the sorted index
+// list and write the updated records to the other pool at the list position, so the records of
+// the paths still in flight are always packed at the front of the current pool.
 enum Plane : int {
     PL_RAY0 = 0, // origin.x, origin.y
     PL_RAY1,     // origin.z, direction.x
@@ -142,23 +145,18 @@ enum Plane : int {
     PL_THR0,     // throughput.x, throughput.y
     PL_THR1,     // throughput.z, scatter_pdf of the last non-virtual sampling event
     PL_SAV0,     // saved_point.x, saved_point.y (origin of that event)
-    PL_SAV1,     // saved_point.z, pending connection: contribution.z
-    PL_COL0,     // radiance gathered so far: r, g
-    PL_COL1,     // radiance b, pending connection: forked random-number key (uint64)
-    PL_IDS,      // uint32 x 4: flags, sample id, next random-number counter, connection info
-    PL_HIT,      // hit distance (double), object index (int32), triangle index (int32, global leaf order)
-    PL_SH0,      // pending connection: direction.x, direction.y
-    PL_SH1,      // direction.z, distance to the sampled light point
-    PL_SH2,      // contribution.x, contribution.y (before emittance and transmittance)
+    PL_SAV1,     // saved_point.z, radiance gathered so far: r
+    PL_COL,      // radiance g, b
+    PL_HIT,      // distance to the vertex to shade (double), flags (uint32), sample id (uint32)
+    PL_IDS,      // uint32 x 4: next random-number counter, object index, triangle index (global leaf order), unused
     N_PLANES
 };
 struct PathPool {
     char* base;
     uint64_t plane_bytes; // capacity * 16
-    uint8_t* cls;         // per record: class of the vertex to shade (0..7), or one of the CLASS_* marks
+    uint8_t* cls;         // per record: class of the vertex to shade (0..7), or CLASS_DONE
 };
 // flags: depth (13 bits) | ray type << 13 | has_hit_surface << 15 | medium << 16
-// connection info: SHADOW_VALID | medium << 16 | light object index
 
 // Per-sample results (PixelData, app/pathtracer.cpp:20-24), indexed by the sample's batch index
 // sid = sample * pixels_in_batch + pixel, so neighbouring lanes hold neighbouring pixels.
@@ -171,9 +169,7 @@ constexpr uint32_t DEPTH_MASK = 0x1FFFu;
 constexpr uint32_t TYPE_SHIFT = 13;
 constexpr uint32_t FLAG_HAS_HIT = 1u << 15;
 constexpr uint32_t MEDIUM_NONE = 0x7FFFu;
-constexpr uint32_t SHADOW_VALID = 1u << 31;
-constexpr uint8_t CLASS_DEAD = 0xFF; // the path has ended; its record still carries a pending connection
-constexpr uint8_t CLASS_DONE = 0xFE; // ended and flushed to the results: nothing left to do
+constexpr uint8_t CLASS_DONE = 0xFF; // the path ended and its radiance is in the results
 
 struct BatchParams {
     int64_t start_idx;    // first pixel
@@ -184,16 +180,16 @@ struct BatchParams {
     uint64_t seed;
 };
 
-// A bounce's records are binned by class without atomics: k_trace leaves per-block class counts,
-// k_bin_scan turns them into offsets (and this summary), k_bin_scatter writes the class-sorted
-// index list.  BIN_CHUNK consecutive records belong to one block in all three.
+// A bounce's records are binned by class without atomics: k_bin_count leaves per-block class
+// counts, k_bin_scan turns them into offsets (and this summary), k_bin_scatter writes the
+// class-sorted index list.  BIN_CHUNK consecutive records belong to one block in all three.
 constexpr int BIN_BLOCK = 256;
 constexpr int BIN_ROUNDS = 8;
 constexpr int BIN_CHUNK = BIN_BLOCK * BIN_ROUNDS;
 struct BinInfo {
     uint32_t start[N_CLASSES]; // first entry of each class segment in the sorted list
     uint32_t count[N_CLASSES];
-    uint32_t total;            // length of the sorted list = records the shade kernels write to the other pool
+    uint32_t total;            // length of the sorted list = records the bounce writes to the other pool
     uint32_t _pad[15];
 };
 

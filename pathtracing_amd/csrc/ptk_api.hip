@@ -172,8 +172,8 @@ struct PtkScene {
     BinInfo* d_info = nullptr;  // [2]: summaries of the previous and the current bounce's lists
     BinInfo* h_info = nullptr;  // pinned ring of INFO_RING summaries read back asynchronously
     hipEvent_t info_events[8] = {};
-    unsigned long long* h_rays = nullptr; // pinned [N_COUNTERS]
-    unsigned long long* d_ray_counter = nullptr;
+    unsigned long long* h_rays = nullptr; // pinned [N_STATISTICS]
+    unsigned long long* d_statistics = nullptr; // STATISTICS_SLOTS per-block slots, then the totals
     std::vector<int> classes; // queue classes present in the scene
     PtkFilm* host_film = nullptr; // scratch film for ptk_render_host
     PtkStats stats{};
@@ -204,23 +204,16 @@ int ensure_capacity(PtkScene* s, int64_t paths) {
 }
 
 // Bytes the kernels are specified to move per item (16-byte planes of the path records, see
-// scene_device.h).  Conservative where the host cannot know a count: the write-back of the radiance
-// after a visible connection is not counted.
-constexpr uint64_t TRACE_BYTES_PER_RECORD = 1;                       // class mark in
-constexpr uint64_t TRACE_BYTES_PER_EXTENSION = 16 + 3 * 16 + 16 + 1; // ids + ray in; hit record + class out
-constexpr uint64_t TRACE_BYTES_PER_CONNECTION = 6 * 16;              // radiance, connection record in
-constexpr uint64_t TRACE_BYTES_PER_PATH = 32;                        // radiance flushed to the results, once
-constexpr uint64_t BIN_BYTES_PER_RECORD = 1;                         // class in
-constexpr uint64_t BIN_BYTES_PER_VERTEX = 4;                         // list entry out
-constexpr uint64_t SHADE_BYTES_PER_VERTEX = 4 + 11 * 16;             // list entry, record in
-constexpr uint64_t SHADE_BYTES_PER_KEPT = 6 * 16 + 1;                // origin, saved.z, radiance, ids, class out
-constexpr uint64_t SHADE_BYTES_PER_FINISHED = 32 + 1;                // radiance flushed, class out
-constexpr uint64_t SHADE_BYTES_PER_CONNECTION = 3 * 16;              // connection record out
-constexpr uint64_t SHADE_BYTES_PER_SURVIVOR = 4 * 16;                // direction, throughput, saved point out
-constexpr uint64_t SHADE_BYTES_PER_PATH = 3 * 16;                    // first-surface position and normal, once
-constexpr uint64_t GENERATE_BYTES_PER_PATH = 10 * 16 + 1 + 3 * 16;   // record, class, zeroed surface results out
-constexpr uint64_t ACCUMULATE_BYTES_PER_PATH = 32 + 3 * 16;          // results in
-constexpr int N_COUNTERS = 4;
+// scene_device.h).
+constexpr uint64_t RECORD_BYTES = N_PLANES * 16;
+constexpr uint64_t BOUNCE_BYTES_PER_VERTEX = 4 + RECORD_BYTES;      // list entry, record in
+constexpr uint64_t BOUNCE_BYTES_PER_CONTINUED = RECORD_BYTES + 1;   // record, class out
+constexpr uint64_t BOUNCE_BYTES_PER_ENDED = 32 + 1;                 // radiance flushed to the results, class out
+constexpr uint64_t BOUNCE_BYTES_PER_PATH = 3 * 16;                  // first-surface position and normal, once
+constexpr uint64_t BIN_BYTES_PER_RECORD = 2;                        // class in, twice (count, scatter)
+constexpr uint64_t BIN_BYTES_PER_VERTEX = 4;                        // list entry out
+constexpr uint64_t GENERATE_BYTES_PER_PATH = RECORD_BYTES + 1 + 3 * 16; // record, class, zeroed surface results out
+constexpr uint64_t ACCUMULATE_BYTES_PER_PATH = 32 + 3 * 16;         // results in
 
 struct EventTimer {
     PtkScene* s;
@@ -253,9 +246,8 @@ struct EventTimer {
             float ms = 0;
             (void) hipEventElapsedTime(&ms, s->events[sp.second.first], s->events[sp.second.second]);
             switch (sp.first) {
-                case 0: s->stats.trace_ms += ms; break;
-                case 1: s->stats.shade_ms += ms; break;
-                case 2: s->stats.bin_ms += ms; break;
+                case 0: s->stats.bounce_ms += ms; break;
+                case 1: s->stats.bin_ms += ms; break;
                 default: s->stats.other_ms += ms; break;
             }
         }
@@ -273,16 +265,16 @@ struct EventTimer {
 int trace_batch(PtkScene* s, const BatchParams& b) {
     EventTimer timer{s};
     PtkStats& st = s->stats;
-    timer.begin(3);
+    HIP_TRY(hipMemsetAsync(s->d_statistics, 0, sizeof(unsigned long long) * N_STATISTICS * (STATISTICS_SLOTS + 1), g_stream));
+    timer.begin(2);
     launch_generate(g_stream, s->dev, b, s->pools[0], s->results, &s->d_info[1]);
     timer.end();
     st.paths += b.n_paths;
     st.algorithmic_bytes += GENERATE_BYTES_PER_PATH * b.n_paths;
-    HIP_TRY(hipMemsetAsync(s->d_ray_counter, 0, N_COUNTERS * sizeof(unsigned long long), g_stream));
 
     uint32_t bound = b.n_paths;     // newest known upper bound of the record count
     uint64_t records = b.n_paths;   // records the oldest unretired bounce walked
-    uint64_t sum_records = 0, sum_shaded = 0;
+    uint64_t sum_records = 0, sum_vertices = 0;
     int launched = 0, retired = 0;
     bool finished = false;
     auto retire = [&](bool wait) -> int { // consumes completed summaries in order
@@ -292,7 +284,7 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
             else if (hipEventQuery(s->info_events[slot]) != hipSuccess) break;
             const uint32_t total = s->h_info[slot].total;
             sum_records += records;
-            sum_shaded += total;
+            sum_vertices += total;
             records = total;
             bound = total;
             if (total == 0) finished = true;
@@ -300,9 +292,8 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
         }
         return PTK_OK;
     };
-    // Bounce `depth` shades the vertices at that depth; one more round than the deepest vertex
-    // finishes the connections the last shade left pending.
-    for (int depth = 0; depth <= s->settings.max_recursion_depth + 1 && !finished; depth++) {
+    // Bounce `depth` shades the vertices at that depth and finds the vertices at depth + 1.
+    for (int depth = 0; depth <= s->settings.max_recursion_depth && !finished; depth++) {
         if (launched - retired == INFO_RING) { // ring full: wait for the oldest summary
             HIP_TRY(hipEventSynchronize(s->info_events[retired % INFO_RING]));
         }
@@ -313,43 +304,37 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
         const PathPool& next = s->pools[(depth + 1) & 1];
         BinInfo* previous = &s->d_info[(depth + 1) & 1];
         BinInfo* info = &s->d_info[depth & 1];
-        timer.begin(0);
-        launch_trace(g_stream, s->dev, b, current, s->results, bound, previous, s->block_counts, s->count_stride, s->d_ray_counter);
-        timer.end();
-        timer.begin(2);
+        timer.begin(1);
         launch_bin(g_stream, s->dev, current, bound, previous, s->block_counts, s->count_stride, info, s->list);
         timer.end();
-        timer.begin(1);
+        timer.begin(0);
         for (int cls : s->classes)
-            launch_shade(g_stream, cls, bound, s->dev, b, current, next, s->results, s->list, info, s->d_ray_counter);
+            launch_bounce(g_stream, cls, bound, s->dev, b, current, next, s->results, s->list, info, s->d_statistics);
         timer.end();
         const int slot = launched % INFO_RING;
         HIP_TRY(hipMemcpyAsync(&s->h_info[slot], info, sizeof(BinInfo), hipMemcpyDeviceToHost, g_stream));
         HIP_TRY(hipEventRecord(s->info_events[slot], g_stream));
         launched++;
         st.bounce_launch_rounds++;
-        st.trace_launches++;
-        st.bin_launches += 2;
-        st.shade_launches += s->classes.size();
+        st.bin_launches += 3;
+        st.bounce_launches += s->classes.size();
     }
-    HIP_TRY(hipMemcpyAsync(s->h_rays, s->d_ray_counter, N_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, g_stream));
+    unsigned long long* totals = s->d_statistics + static_cast<size_t>(N_STATISTICS) * STATISTICS_SLOTS;
+    launch_sum_statistics(g_stream, s->d_statistics, totals);
+    HIP_TRY(hipMemcpyAsync(s->h_rays, totals, N_STATISTICS * sizeof(unsigned long long), hipMemcpyDeviceToHost, g_stream));
     int rc = retire(true);
     if (rc != PTK_OK) return rc;
     HIP_TRY(hipStreamSynchronize(g_stream));
-    const uint64_t segments = s->h_rays[0], extensions = s->h_rays[1], connections = s->h_rays[2], done_in_shade = s->h_rays[3];
+    const uint64_t segments = s->h_rays[0], extensions = s->h_rays[1] + b.n_paths, continued = s->h_rays[3];
     st.shadow_rays += segments;
     st.extension_rays += extensions;
-    st.vertices += sum_shaded;
-    const uint64_t tb = TRACE_BYTES_PER_RECORD * sum_records + TRACE_BYTES_PER_EXTENSION * extensions +
-                        TRACE_BYTES_PER_CONNECTION * connections + TRACE_BYTES_PER_PATH * (b.n_paths - done_in_shade);
-    const uint64_t bb = BIN_BYTES_PER_RECORD * sum_records + BIN_BYTES_PER_VERTEX * sum_shaded;
-    const uint64_t sb = SHADE_BYTES_PER_VERTEX * sum_shaded + SHADE_BYTES_PER_KEPT * (sum_shaded - done_in_shade) +
-                        SHADE_BYTES_PER_FINISHED * done_in_shade + SHADE_BYTES_PER_CONNECTION * connections +
-                        SHADE_BYTES_PER_SURVIVOR * (extensions - b.n_paths) + SHADE_BYTES_PER_PATH * b.n_paths;
-    st.trace_bytes += tb;
-    st.shade_bytes += sb;
+    st.vertices += sum_vertices;
+    const uint64_t bb = BIN_BYTES_PER_RECORD * sum_records + BIN_BYTES_PER_VERTEX * sum_vertices;
+    const uint64_t sb = BOUNCE_BYTES_PER_VERTEX * sum_vertices + BOUNCE_BYTES_PER_CONTINUED * continued +
+                        BOUNCE_BYTES_PER_ENDED * (sum_vertices - continued) + BOUNCE_BYTES_PER_PATH * b.n_paths;
+    st.bounce_bytes += sb;
     st.bin_bytes += bb;
-    st.algorithmic_bytes += tb + bb + sb;
+    st.algorithmic_bytes += bb + sb;
     timer.collect();
     return PTK_OK;
 }
@@ -737,9 +722,9 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     HIP_TRY(buf.upload(&dev.light_cumulative_area, light_area));
     HIP_TRY(buf.upload(&dev.light_tri_index, light_tri));
     HIP_TRY(buf.alloc(&s->d_info, 2));
-    HIP_TRY(buf.alloc(&s->d_ray_counter, N_COUNTERS)); // see launch_trace
+    HIP_TRY(buf.alloc(&s->d_statistics, static_cast<size_t>(N_STATISTICS) * (STATISTICS_SLOTS + 1)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_info), INFO_RING * sizeof(BinInfo), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_rays), N_COUNTERS * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_rays), N_STATISTICS * sizeof(unsigned long long), hipHostMallocDefault));
     for (int i = 0; i < INFO_RING; i++) HIP_TRY(hipEventCreateWithFlags(&s->info_events[i], hipEventDisableTiming));
     *out = s.release();
     return PTK_OK;
