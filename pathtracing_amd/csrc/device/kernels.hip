@@ -445,7 +445,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
             const int obj = static_cast<int>(ids.y);
             const int prim = static_cast<int>(ids.z);
             const DevObject& o = sc.objects[obj];
-            const DevMaterial& m = sc.materials[o.material];
+            const DevMaterial& m = o.mat;
             Surface s;
             s.point = point;
             s.incident = dir;

@@ -43,6 +43,10 @@ struct DevMaterial {
     int32_t internal_medium, external_medium;                    // -1 = none
     int32_t _pad;
     double n, k;
+    // first texel of each map (the whole map when it is 1x1): what shading reads when texture
+    // coordinates are not in play, without walking maps -> map_data
+    double c_albedo[3], c_emittance[3]; // emittance = emission colour * light intensity
+    double c_roughness, c_transparency;
 };
 
 struct DevObject {
@@ -59,6 +63,8 @@ struct DevObject {
     int32_t n_light_tris;    // mesh of a light material: number of triangles, else 0
     int64_t light_table;     // mesh light: offset of its cumulative-area / index tables
     double mesh_light_area;  // mesh light: last cumulative area
+    int32_t index, _pad2;    // position in the scene's object table
+    DevMaterial mat;         // copy of materials[material]: one load reaches everything shading needs
 };
 
 // What the closest-hit loop reads per object: 128 bytes fetched by two scalar loads.
@@ -121,6 +127,7 @@ struct DevScene {
     const DevMap* maps;
     const double* map_data;
     const int32_t* lights;       // object indices of light objects, in scene order
+    const DevObject* light_objects; // copies of those objects, same order
     const TriHot* tri_hot;
     const TriCold* tri_cold;
     const BvhNode4* nodes;

@@ -26,7 +26,7 @@ PTK_DEV double medium_ior(const DevScene& sc, int medium) {
 
 // Material::sample_transparency_map (src/materials.cpp:76-81): always consumes one number.
 PTK_DEV bool sample_transparency(const DevScene& sc, const DevMaterial& m, const Surface& s, Rng& rng) {
-    double transparency = tex1(sc, m.transparency, s.use_uv, s.u, s.v);
+    double transparency = s.use_uv ? tex1(sc, m.transparency, true, s.u, s.v) : m.c_transparency;
     return rng.u01() <= transparency;
 }
 
@@ -38,11 +38,16 @@ PTK_DEV bool allow_direct_light(const DevScene& sc, const DevMaterial& m, const 
 }
 
 PTK_DEV V3 material_emittance(const DevScene& sc, const DevMaterial& m, bool use_uv, double u, double v) { // :72-74
+    if (!use_uv) return v3(m.c_emittance);
     return tex3(sc, m.emission, use_uv, u, v) * tex1(sc, m.intensity, use_uv, u, v);
 }
 
+PTK_DEV V3 material_albedo(const DevScene& sc, const DevMaterial& m, const Surface& s) {
+    return s.use_uv ? tex3(sc, m.albedo, true, s.u, s.v) : v3(m.c_albedo);
+}
+
 PTK_DEV double get_alpha(const DevScene& sc, const DevMaterial& m, const Surface& s) { // :185-188
-    return fmax(tex1(sc, m.roughness, s.use_uv, s.u, s.v), EPSILON);
+    return fmax(s.use_uv ? tex1(sc, m.roughness, true, s.u, s.v) : m.c_roughness, EPSILON);
 }
 
 PTK_DEV double specular_pdf(const DevScene& sc, const DevMaterial& m, const Surface& s, const V3& outgoing) { // :241-247
@@ -74,7 +79,7 @@ template<int T>
 PTK_DEV V3 material_eval(const DevScene& sc, const DevMaterial& m, const Surface& s, const V3& outgoing, Rng& rng) {
     if (T == PTK_MAT_DIFFUSE) { // :83-88
         if (sample_transparency(sc, m, s, rng)) return v3(0.0);
-        return tex3(sc, m.albedo, s.use_uv, s.u, s.v) / PI;
+        return material_albedo(sc, m, s) / PI;
     }
     if (T == PTK_MAT_GLOSSY) { // :249-286
         if (sample_transparency(sc, m, s, rng)) return v3(0.0);
@@ -93,7 +98,7 @@ PTK_DEV V3 material_eval(const DevScene& sc, const DevMaterial& m, const Surface
         double R_0 = r0s * r0s;
         double fac1 = fmin(1.0 - dot(s.normal, -s.incident) / 2.0, 1.0);
         double fac2 = fmin(1.0 - dot(s.normal, outgoing) / 2.0, 1.0);
-        V3 albedo = tex3(sc, m.albedo, s.use_uv, s.u, s.v);
+        V3 albedo = material_albedo(sc, m, s);
         V3 diffuse = albedo * 28.0 / (23.0 * PI) * (1 - R_0) * (1 - fac1 * fac1 * fac1 * fac1 * fac1) *
                      (1 - fac2 * fac2 * fac2 * fac2 * fac2);
         V3 reflection_color = m.is_dielectric ? v3(1.0) : albedo;
@@ -115,12 +120,12 @@ PTK_DEV V3 material_eval(const DevScene& sc, const DevMaterial& m, const Surface
             k2 = 0;
         }
         double F_r = fresnel_multiplier(-dot(s.incident, h), n1, k1, n2, k2, false);
-        return tex3(sc, m.albedo, s.use_uv, s.u, s.v) * (F_r * microfacet_core(sc, m, s, h, outgoing));
+        return material_albedo(sc, m, s) * (F_r * microfacet_core(sc, m, s, h, outgoing));
     }
     if (T == PTK_MAT_REFLECTIVE_MICROFACET) { // :390-404
         if (sample_transparency(sc, m, s, rng)) return v3(0.0);
         V3 h = normalize(outgoing - s.incident);
-        return tex3(sc, m.albedo, s.use_uv, s.u, s.v) * microfacet_core(sc, m, s, h, outgoing);
+        return material_albedo(sc, m, s) * microfacet_core(sc, m, s, h, outgoing);
     }
     return v3(0.0); // Reflective :108-110, Transparent :138-140, TransparentMicrofacet :406-408
 }
@@ -137,13 +142,13 @@ PTK_DEV BrdfSample material_sample(const DevScene& sc, const DevMaterial& m, con
     }
     if (T == PTK_MAT_DIFFUSE) { // :90-101
         r.outgoing = sample_cosine_hemisphere(s.normal, rng);
-        r.weight = tex3(sc, m.albedo, s.use_uv, s.u, s.v);
+        r.weight = material_albedo(sc, m, s);
         r.pdf = material_pdf<T>(sc, m, s, r.outgoing);
         r.type = RAY_DIFFUSE;
     }
     else if (T == PTK_MAT_REFLECTIVE) { // :112-123
         r.outgoing = reflect_vector(s.incident, s.normal);
-        r.weight = m.is_dielectric ? v3(1.0) : tex3(sc, m.albedo, s.use_uv, s.u, s.v);
+        r.weight = m.is_dielectric ? v3(1.0) : material_albedo(sc, m, s);
         r.pdf = 0;
         r.type = RAY_REFLECTED;
     }
@@ -326,9 +331,10 @@ struct LightSample {
 template<bool TRIS>
 PTK_DEV bool pick_light_point(const DevScene& sc, int shaded_object, const V3& from, LightSample& ls, Rng& rng) {
     if (sc.n_lights == 0) return false;                                   // sample_random_light :444-462
-    ls.light_index = sc.lights[rng.integer(0, sc.n_lights)];
+    const DevObject& light = sc.light_objects[rng.integer(0, sc.n_lights)];
+    ls.light_index = light.index;
     if (ls.light_index == shaded_object) return false;
-    V3 p = random_light_point<TRIS>(sc, sc.objects[ls.light_index], from, ls.light_pdf, rng);
+    V3 p = random_light_point<TRIS>(sc, light, from, ls.light_pdf, rng);
     if (ls.light_pdf == 0) return false;
     V3 d = p - from;
     ls.distance = len(d);
@@ -352,7 +358,7 @@ PTK_DEV V3 march_to_light(const DevScene& sc, V3 org, const V3& dir, int medium,
         if (medium < 0) medium = sc.background_medium;
         transmittance = transmittance * medium_transmittance(sc.media[medium], h.t);
         const DevObject& o = sc.objects[h.obj];
-        const DevMaterial& m = sc.materials[o.material];
+        const DevMaterial& m = o.mat;
         V3 point = org + dir * h.t;
         Surface s;
         s.use_uv = UV && m.needs_uv != 0;

@@ -498,6 +498,15 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
         m.internal_medium = pm.internal_medium;
         m.external_medium = pm.external_medium;
         m.needs_uv = map_big(m.albedo) || map_big(m.emission) || map_big(m.intensity) || map_big(m.roughness) || map_big(m.transparency);
+        // first texels (ValueMap::get with no texture coordinates reads element 0; a missing map reads as 0)
+        auto texel = [&](int id, int channel) { return id < 0 ? 0.0 : d->map_data[d->maps[id].offset + channel]; };
+        const double intensity = texel(m.intensity, 0);
+        for (int c = 0; c < 3; c++) {
+            m.c_albedo[c] = texel(m.albedo, c);
+            m.c_emittance[c] = texel(m.emission, c) * intensity; // Material::get_light_emittance src/materials.cpp:72-74
+        }
+        m.c_roughness = texel(m.roughness, 0);
+        m.c_transparency = texel(m.transparency, 0);
         materials[static_cast<size_t>(i)] = m;
     }
 
@@ -519,6 +528,8 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
         o.material = po.material;
         o.is_light = materials[static_cast<size_t>(po.material)].is_light;
         o.bvh_root = -1;
+        o.index = i;
+        o.mat = materials[static_cast<size_t>(po.material)];
         class_mask |= 1u << materials[static_cast<size_t>(po.material)].type;
         if (o.is_light) lights.push_back(i);
         switch (po.type) {
@@ -716,6 +727,9 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     HIP_TRY(buf.upload(&dev.maps, maps));
     HIP_TRY(buf.upload(&dev.map_data, map_data));
     HIP_TRY(buf.upload(&dev.lights, lights));
+    std::vector<DevObject> light_objects;
+    for (int32_t i : lights) light_objects.push_back(objects[static_cast<size_t>(i)]);
+    HIP_TRY(buf.upload(&dev.light_objects, light_objects));
     HIP_TRY(buf.upload(&dev.tri_hot, tri_hot));
     HIP_TRY(buf.upload(&dev.tri_cold, tri_cold));
     HIP_TRY(buf.upload(&dev.nodes, nodes));
