@@ -131,8 +131,10 @@ PTK_DEV void add_block_statistics(unsigned long long* slots, uint32_t (*wave_sum
 #pragma unroll
     for (int k = 0; k < N_STATISTICS; k++)
         for (int off = 32; off > 0; off >>= 1) mine[k] += __shfl_down(mine[k], off);
-    if ((threadIdx.x & 63) == 0)
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
         for (int k = 0; k < N_STATISTICS; k++) wave_sums[threadIdx.x >> 6][k] = mine[k];
+    }
     __syncthreads();
     if (threadIdx.x < N_STATISTICS) {
         uint32_t total = 0;
@@ -358,6 +360,25 @@ __global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathPool pool, const BinI
         if (classes[r] >= 0) list_out[counts[r][wave][classes[r]] + below[r]] = blockIdx.x * BIN_CHUNK + r * BLOCK + threadIdx.x;
 }
 
+struct Record { // the ten planes of one path record
+    double2 r0, r1, r2, t0, t1, v0, v1, cc;
+    uint4 hit, ids;
+};
+PTK_DEV Record load_record(const PathPool& p, uint32_t i) {
+    Record r;
+    r.r0 = ld2(p, PL_RAY0, i);
+    r.r1 = ld2(p, PL_RAY1, i);
+    r.r2 = ld2(p, PL_RAY2, i);
+    r.t0 = ld2(p, PL_THR0, i);
+    r.t1 = ld2(p, PL_THR1, i);
+    r.v0 = ld2(p, PL_SAV0, i);
+    r.v1 = ld2(p, PL_SAV1, i);
+    r.cc = ld2(p, PL_COL, i);
+    r.hit = ldu4(p, PL_HIT, i);
+    r.ids = ldu4(p, PL_IDS, i);
+    return r;
+}
+
 // -------------------------------------------------------------------------------------------------
 // One vertex of every path whose current vertex has class CLS: the loop body of raytrace
 // (app/pathtracer.cpp:69-171) followed by the head of its next iteration (:53-67).  Reads record
@@ -375,15 +396,20 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
     const uint32_t first = info->start[CLS];
     uint32_t stat[N_STATISTICS] = {0, 0, 0, 0};
     if (blockIdx.x * BLOCK >= n) return;
-    for (uint32_t qi = blockIdx.x * BLOCK + threadIdx.x; qi < n; qi += gridDim.x * BLOCK) {
+    // Software pipeline over the grid-stride loop: the record of the next iteration is requested in
+    // the middle of the current one (after the table lookups of shading, before the two ray casts),
+    // and its list entry one iteration earlier still, so neither latency is paid at the loop top.
+    const uint32_t stride = gridDim.x * BLOCK;
+    uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
+    bool have = qi < n;
+    Record cur{};
+    if (have) cur = load_record(in, list[first + qi]);
+    uint32_t src_next = qi + stride < n ? list[first + qi + stride] : 0u;
+    for (; have; qi += stride) {
         const uint32_t dst = first + qi;
-        const uint32_t src = list[dst];
-        const double2 r0 = ld2(in, PL_RAY0, src), r1 = ld2(in, PL_RAY1, src), r2 = ld2(in, PL_RAY2, src);
-        const double2 t0 = ld2(in, PL_THR0, src), t1 = ld2(in, PL_THR1, src);
-        const double2 v0 = ld2(in, PL_SAV0, src), v1 = ld2(in, PL_SAV1, src);
-        const double2 cc = ld2(in, PL_COL, src);
-        const uint4 hit = ldu4(in, PL_HIT, src);
-        const uint4 ids = ldu4(in, PL_IDS, src);
+        const bool have_next = qi + stride < n;
+        const double2 r0 = cur.r0, r1 = cur.r1, r2 = cur.r2, t0 = cur.t0, t1 = cur.t1, v0 = cur.v0, v1 = cur.v1, cc = cur.cc;
+        const uint4 hit = cur.hit, ids = cur.ids;
         V3 org = v3(r0.x, r0.y, r1.x);
         V3 dir = v3(r1.y, r2.x, r2.y);
         V3 thr = v3(t0.x, t0.y, t1.x);
@@ -518,6 +544,11 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
         }
         const bool alive = allow && static_cast<int>(depth) + 1 <= sc.max_depth;
 
+        // request the next iteration's record and the list entry of the one after
+        Record nxt{};
+        if (have_next) nxt = load_record(in, src_next);
+        const uint32_t src_after = qi + 2 * stride < n ? list[first + qi + 2 * stride] : 0u;
+
         // the connection: compute_visibility (src/objects.cpp:470-513) and the acceptance test of
         // sample_light (:558), on its own forked random-number stream
         if (connect) {
@@ -539,8 +570,8 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
         if (nv.cls < 0) { // the path ended here
             flush_color(res, sid, color.x, color.y, color.z);
             out.cls[dst] = CLASS_DONE;
-            continue;
         }
+        else {
         stat[3]++;
         st2(out, PL_RAY0, dst, point.x, point.y);
         st2(out, PL_RAY1, dst, point.z, n_dir.x);
@@ -554,6 +585,10 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
              (depth + 1) | (ray_type << TYPE_SHIFT) | (has_hit ? FLAG_HAS_HIT : 0u) | (medium_bits << 16), sid);
         stu4(out, PL_IDS, dst, rng.ctr, static_cast<uint32_t>(nv.obj), static_cast<uint32_t>(nv.prim), 0u);
         out.cls[dst] = static_cast<uint8_t>(nv.cls);
+        }
+        cur = nxt;
+        src_next = src_after;
+        have = have_next;
     }
     add_block_statistics(statistics, wave_sums, stat);
 }
