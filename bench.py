@@ -69,14 +69,15 @@ def cpu_baseline(host_scene, args, threads):
     osc = ob.OracleScene(host_scene)
     image, pos, nrm = np.zeros((H, W, 3)), np.zeros((H, W, 3)), np.zeros((H, W, 3))
     cnt = np.zeros((H, W), dtype=np.uint64)
-    # calibrate on a thin slice, then size the sample for roughly 15 s
+    # calibrate on a thin slice, then size the sample for roughly 12 s
     rows = max(1, H // 135)
     job = pt.make_job(0, rows * W, 1, 0, args.seed)
     t0 = time.perf_counter()
     osc.render(job, image, pos, nrm, cnt, threads=threads)
     rate = rows * W / max(time.perf_counter() - t0, 1e-9)
-    spp = int(max(1, min(8, rate * 15.0 / (W * H))))
-    n_pixels = W * H if rate * 15.0 >= W * H else int(max(W, (rate * 15.0) // W * W))
+    budget = rate * 12.0  # paths
+    spp = int(max(1, min(256, budget / (W * H))))
+    n_pixels = W * H if budget >= W * H else int(max(W, budget // W * W))
     job = pt.make_job(0, n_pixels, spp, 1, args.seed)
     t0 = time.perf_counter()
     osc.render(job, image, pos, nrm, cnt, threads=threads)
@@ -137,11 +138,14 @@ def main():
     total_spp = spp * (args.warmup + args.steps)
     offset, _ = sample_slice(rank, world, total_spp * world)
 
-    # Kernel families are timed with HIP events on the library's stream on every PROFILE_EVERY-th step
-    # of the timed region (event records drain the queue, so timing every step would slow the run).
+    # Kernels are timed with HIP events on the library's stream on every PROFILE_EVERY-th step of the
+    # timed region (event records drain the queue, so timing every step would slow the run).
     PROFILE_EVERY = 4
+    CLASS_NAMES = ["Diffuse", "Reflective", "Transparent", "Glossy", "MetallicMicrofacet", "ReflectiveMicrofacet",
+                   "TransparentMicrofacet", "MediumScatter"]
     profiled = {"steps": 0}
-    fam = {k: [0.0, 0, 0] for k in ("k_bounce", "k_bin")}
+    per_class = [[0.0, 0, 0, 0] for _ in range(8)]  # ms, bytes, launches, vertices
+    fam = {"k_bounce": 0.0, "k_bin": 0.0, "other": 0.0}
 
     def step(i, timed=False):
         job = pt.make_job(0, n_pixels, spp, offset + i * spp, args.seed)
@@ -152,10 +156,14 @@ def main():
             pt.set_profiling(False)
             s1 = scene.stats()
             profiled["steps"] += 1
-            for k, f in (("k_bounce", "bounce"), ("k_bin", "bin")):
-                fam[k][0] += getattr(s1, f + "_ms") - getattr(s0, f + "_ms")
-                fam[k][1] += getattr(s1, f + "_bytes") - getattr(s0, f + "_bytes")
-                fam[k][2] += getattr(s1, f + "_launches") - getattr(s0, f + "_launches")
+            for c in range(8):
+                per_class[c][0] += s1.class_ms[c] - s0.class_ms[c]
+                per_class[c][1] += s1.class_bytes[c] - s0.class_bytes[c]
+                per_class[c][2] += s1.class_launches[c] - s0.class_launches[c]
+                per_class[c][3] += s1.class_vertices[c] - s0.class_vertices[c]
+            fam["k_bounce"] += s1.bounce_ms - s0.bounce_ms
+            fam["k_bin"] += s1.bin_ms - s0.bin_ms
+            fam["other"] += s1.other_ms - s0.other_ms
         else:
             scene.render(film, job)
 
@@ -187,24 +195,32 @@ def main():
     total_paths = paths_per_rank * world
     value = total_paths / elapsed / 1e6
 
-    # dominant kernel family by device time (HIP events on the library's stream, this timed region)
-    families = {k: tuple(v) for k, v in fam.items()}
-    dominant = max(families, key=lambda k: families[k][0])
-    d_ms, d_bytes, d_launches = families[dominant]
-    achieved = (d_bytes / max(d_launches, 1)) / (d_ms / max(d_launches, 1) * 1e-3) / 1e9 if d_ms > 0 else 0.0
+    # dominant kernel by device time (HIP events on the library's stream, profiled steps of this timed
+    # region): one instantiation of k_bounce, named as rocprofv3 shows it
+    dom = max(range(8), key=lambda c: per_class[c][0])
+    d_ms, d_bytes, d_launches, d_vertices = per_class[dom]
+    hs = host_scene.desc
+    tris = "true" if hs.n_triangles > 0 else "false"
+    def big(i):
+        return i >= 0 and (hs.maps[i].width > 1 or hs.maps[i].height > 1)
+    uv = "true" if any(big(m) for k in range(hs.n_materials)
+                       for m in (hs.materials[k].albedo_map, hs.materials[k].emission_color_map, hs.materials[k].light_intensity_map,
+                                 hs.materials[k].roughness_map, hs.materials[k].transparency_map)) else "false"
+    kernel = f"ptk::k_bounce<{dom}, {tris}, {uv}>"
+    achieved = d_bytes / (d_ms * 1e-3) / 1e9 if d_ms > 0 else 0.0
     traffic = None
     traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(traffic_file):
         try:
             with open(traffic_file) as f:
-                traffic = json.load(f).get(args.workload, {}).get(dominant)
+                traffic = json.load(f).get(args.workload, {}).get(kernel)
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+    roofline = {"bound": "hbm", "kernel": kernel, "class": CLASS_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_launch": d_bytes / max(d_launches, 1), "ms_per_launch": d_ms / max(d_launches, 1),
-                "launches": int(d_launches), "profiled_steps": profiled["steps"],
-                "device_ms": {k: v[0] for k, v in families.items()}}
+                "vertices_per_launch": d_vertices / max(d_launches, 1), "launches": int(d_launches),
+                "profiled_steps": profiled["steps"], "device_ms": dict(fam)}
 
     out = {
         "metric": "Mpaths/s (whole node) at 1080p, scenes/example + 1M-tri mesh, 1/2/4/8 GPUs",

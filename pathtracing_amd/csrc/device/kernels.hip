@@ -394,7 +394,18 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
     TraversalStack st = make_stack(lds_stack);
     const uint32_t n = info->count[CLS];
     const uint32_t first = info->start[CLS];
-    uint32_t stat[N_STATISTICS] = {0, 0, 0, 0};
+    uint32_t stat[N_STATISTICS] = {};
+#ifdef PTK_STAMPS
+#define PTK_STAMP(k)                                                        \
+    {                                                                       \
+        const uint64_t now_ = __builtin_readcyclecounter();                 \
+        if ((threadIdx.x & 63) == 0) stat[4 + (k)] += static_cast<uint32_t>((now_ - stamp_) >> 4); \
+        stamp_ = now_;                                                      \
+    }
+    uint64_t stamp_ = __builtin_readcyclecounter();
+#else
+#define PTK_STAMP(k)
+#endif
     if (blockIdx.x * BLOCK >= n) return;
     // Software pipeline over the grid-stride loop: the record of the next iteration is requested in
     // the middle of the current one (after the table lookups of shading, before the two ray casts),
@@ -544,6 +555,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
         }
         const bool alive = allow && static_cast<int>(depth) + 1 <= sc.max_depth;
 
+        PTK_STAMP(0)
         // request the next iteration's record and the list entry of the one after
         Record nxt{};
         if (have_next) nxt = load_record(in, src_next);
@@ -558,6 +570,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
             color = color + sh_contrib * visible;
         }
 
+        PTK_STAMP(1)
         // the head of the next loop iteration: where does the new ray end
         Vertex nv;
         nv.cls = -1;
@@ -567,6 +580,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
             nv = next_vertex<TRIS>(sc, b, point, n_dir, medium_bits, sid, rng.ctr, st);
             if (nv.cls < 0 && !sc.background_is_black) color = color + thr * v3(sc.background);
         }
+        PTK_STAMP(2)
         if (nv.cls < 0) { // the path ended here
             flush_color(res, sid, color.x, color.y, color.z);
             out.cls[dst] = CLASS_DONE;
@@ -589,6 +603,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
         cur = nxt;
         src_next = src_after;
         have = have_next;
+        PTK_STAMP(3)
     }
     add_block_statistics(statistics, wave_sums, stat);
 }

@@ -172,8 +172,8 @@ struct PtkScene {
     BinInfo* d_info = nullptr;  // [2]: summaries of the previous and the current bounce's lists
     BinInfo* h_info = nullptr;  // pinned ring of INFO_RING summaries read back asynchronously
     hipEvent_t info_events[8] = {};
-    unsigned long long* h_rays = nullptr; // pinned [N_STATISTICS]
-    unsigned long long* d_statistics = nullptr; // STATISTICS_SLOTS per-block slots, then the totals
+    unsigned long long* h_rays = nullptr; // pinned [N_CLASSES][N_STATISTICS]
+    unsigned long long* d_statistics = nullptr; // per class STATISTICS_SLOTS per-block slots, then per-class totals
     std::vector<int> classes; // queue classes present in the scene
     PtkFilm* host_film = nullptr; // scratch film for ptk_render_host
     PtkStats stats{};
@@ -214,6 +214,9 @@ constexpr uint64_t BIN_BYTES_PER_RECORD = 2;                        // class in,
 constexpr uint64_t BIN_BYTES_PER_VERTEX = 4;                        // list entry out
 constexpr uint64_t GENERATE_BYTES_PER_PATH = RECORD_BYTES + 1 + 3 * 16; // record, class, zeroed surface results out
 constexpr uint64_t ACCUMULATE_BYTES_PER_PATH = 32 + 3 * 16;         // results in
+// per-class statistics slots, then per-class totals
+constexpr size_t STATISTICS_VALUES = static_cast<size_t>(N_CLASSES) * N_STATISTICS * (STATISTICS_SLOTS + 1);
+constexpr size_t STATISTICS_BYTES = STATISTICS_VALUES * sizeof(unsigned long long);
 
 struct EventTimer {
     PtkScene* s;
@@ -248,6 +251,10 @@ struct EventTimer {
             switch (sp.first) {
                 case 0: s->stats.bounce_ms += ms; break;
                 case 1: s->stats.bin_ms += ms; break;
+                case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15:
+                    s->stats.class_ms[sp.first - 8] += ms;
+                    s->stats.bounce_ms += ms;
+                    break;
                 default: s->stats.other_ms += ms; break;
             }
         }
@@ -265,7 +272,7 @@ struct EventTimer {
 int trace_batch(PtkScene* s, const BatchParams& b) {
     EventTimer timer{s};
     PtkStats& st = s->stats;
-    HIP_TRY(hipMemsetAsync(s->d_statistics, 0, sizeof(unsigned long long) * N_STATISTICS * (STATISTICS_SLOTS + 1), g_stream));
+    HIP_TRY(hipMemsetAsync(s->d_statistics, 0, STATISTICS_BYTES, g_stream));
     timer.begin(2);
     launch_generate(g_stream, s->dev, b, s->pools[0], s->results, &s->d_info[1]);
     timer.end();
@@ -275,6 +282,7 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
     uint32_t bound = b.n_paths;     // newest known upper bound of the record count
     uint64_t records = b.n_paths;   // records the oldest unretired bounce walked
     uint64_t sum_records = 0, sum_vertices = 0;
+    uint64_t class_vertices[N_CLASSES] = {};
     int launched = 0, retired = 0;
     bool finished = false;
     auto retire = [&](bool wait) -> int { // consumes completed summaries in order
@@ -285,6 +293,7 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
             const uint32_t total = s->h_info[slot].total;
             sum_records += records;
             sum_vertices += total;
+            for (int c = 0; c < N_CLASSES; c++) class_vertices[c] += s->h_info[slot].count[c];
             records = total;
             bound = total;
             if (total == 0) finished = true;
@@ -307,10 +316,13 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
         timer.begin(1);
         launch_bin(g_stream, s->dev, current, bound, previous, s->block_counts, s->count_stride, info, s->list);
         timer.end();
-        timer.begin(0);
-        for (int cls : s->classes)
-            launch_bounce(g_stream, cls, bound, s->dev, b, current, next, s->results, s->list, info, s->d_statistics);
-        timer.end();
+        for (int cls : s->classes) {
+            timer.begin(8 + cls);
+            launch_bounce(g_stream, cls, bound, s->dev, b, current, next, s->results, s->list, info,
+                          s->d_statistics + static_cast<size_t>(cls) * N_STATISTICS * STATISTICS_SLOTS);
+            timer.end();
+            st.class_launches[cls]++;
+        }
         const int slot = launched % INFO_RING;
         HIP_TRY(hipMemcpyAsync(&s->h_info[slot], info, sizeof(BinInfo), hipMemcpyDeviceToHost, g_stream));
         HIP_TRY(hipEventRecord(s->info_events[slot], g_stream));
@@ -319,22 +331,37 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
         st.bin_launches += 3;
         st.bounce_launches += s->classes.size();
     }
-    unsigned long long* totals = s->d_statistics + static_cast<size_t>(N_STATISTICS) * STATISTICS_SLOTS;
-    launch_sum_statistics(g_stream, s->d_statistics, totals);
-    HIP_TRY(hipMemcpyAsync(s->h_rays, totals, N_STATISTICS * sizeof(unsigned long long), hipMemcpyDeviceToHost, g_stream));
+    unsigned long long* totals = s->d_statistics + static_cast<size_t>(N_CLASSES) * N_STATISTICS * STATISTICS_SLOTS;
+    for (int cls : s->classes)
+        launch_sum_statistics(g_stream, s->d_statistics + static_cast<size_t>(cls) * N_STATISTICS * STATISTICS_SLOTS,
+                              totals + cls * N_STATISTICS);
+    HIP_TRY(hipMemcpyAsync(s->h_rays, totals, N_CLASSES * N_STATISTICS * sizeof(unsigned long long), hipMemcpyDeviceToHost, g_stream));
     int rc = retire(true);
     if (rc != PTK_OK) return rc;
     HIP_TRY(hipStreamSynchronize(g_stream));
-    const uint64_t segments = s->h_rays[0], extensions = s->h_rays[1] + b.n_paths, continued = s->h_rays[3];
+    uint64_t segments = 0, extensions = b.n_paths, bounce_bytes = BOUNCE_BYTES_PER_PATH * b.n_paths;
+    for (int cls : s->classes) {
+        const unsigned long long* t = s->h_rays + cls * N_STATISTICS;
+        segments += t[0];
+        extensions += t[1];
+        const uint64_t continued = t[3], vertices = class_vertices[cls];
+        const uint64_t bytes = BOUNCE_BYTES_PER_VERTEX * vertices + BOUNCE_BYTES_PER_CONTINUED * continued +
+                               BOUNCE_BYTES_PER_ENDED * (vertices - continued);
+        st.class_vertices[cls] += vertices;
+        st.class_bytes[cls] += bytes;
+        bounce_bytes += bytes;
+#ifdef PTK_STAMPS
+        std::fprintf(stderr, "class %d stamps (wave-cycles/16): shade %llu march %llu extend %llu store %llu; vertices %llu\n", cls, t[4], t[5],
+                     t[6], t[7], (unsigned long long) vertices);
+#endif
+    }
     st.shadow_rays += segments;
     st.extension_rays += extensions;
     st.vertices += sum_vertices;
     const uint64_t bb = BIN_BYTES_PER_RECORD * sum_records + BIN_BYTES_PER_VERTEX * sum_vertices;
-    const uint64_t sb = BOUNCE_BYTES_PER_VERTEX * sum_vertices + BOUNCE_BYTES_PER_CONTINUED * continued +
-                        BOUNCE_BYTES_PER_ENDED * (sum_vertices - continued) + BOUNCE_BYTES_PER_PATH * b.n_paths;
-    st.bounce_bytes += sb;
+    st.bounce_bytes += bounce_bytes;
     st.bin_bytes += bb;
-    st.algorithmic_bytes += bb + sb;
+    st.algorithmic_bytes += bb + bounce_bytes;
     timer.collect();
     return PTK_OK;
 }
@@ -736,9 +763,9 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     HIP_TRY(buf.upload(&dev.light_cumulative_area, light_area));
     HIP_TRY(buf.upload(&dev.light_tri_index, light_tri));
     HIP_TRY(buf.alloc(&s->d_info, 2));
-    HIP_TRY(buf.alloc(&s->d_statistics, static_cast<size_t>(N_STATISTICS) * (STATISTICS_SLOTS + 1)));
+    HIP_TRY(buf.alloc(&s->d_statistics, STATISTICS_VALUES));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_info), INFO_RING * sizeof(BinInfo), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_rays), N_STATISTICS * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_rays), N_CLASSES * N_STATISTICS * sizeof(unsigned long long), hipHostMallocDefault));
     for (int i = 0; i < INFO_RING; i++) HIP_TRY(hipEventCreateWithFlags(&s->info_events[i], hipEventDisableTiming));
     *out = s.release();
     return PTK_OK;
