@@ -144,8 +144,8 @@ def main():
     CLASS_NAMES = ["Diffuse", "Reflective", "Transparent", "Glossy", "MetallicMicrofacet", "ReflectiveMicrofacet",
                    "TransparentMicrofacet", "MediumScatter"]
     profiled = {"steps": 0}
-    per_class = [[0.0, 0, 0, 0] for _ in range(8)]  # ms, bytes, launches, vertices
-    fam = {"k_bounce": 0.0, "k_bin": 0.0, "other": 0.0}
+    fam = {"k_bounce": [0.0, 0, 0], "k_bin": [0.0, 0, 0]}  # ms, bytes, launches
+    other_ms = [0.0]
 
     def step(i, timed=False):
         job = pt.make_job(0, n_pixels, spp, offset + i * spp, args.seed)
@@ -156,14 +156,11 @@ def main():
             pt.set_profiling(False)
             s1 = scene.stats()
             profiled["steps"] += 1
-            for c in range(8):
-                per_class[c][0] += s1.class_ms[c] - s0.class_ms[c]
-                per_class[c][1] += s1.class_bytes[c] - s0.class_bytes[c]
-                per_class[c][2] += s1.class_launches[c] - s0.class_launches[c]
-                per_class[c][3] += s1.class_vertices[c] - s0.class_vertices[c]
-            fam["k_bounce"] += s1.bounce_ms - s0.bounce_ms
-            fam["k_bin"] += s1.bin_ms - s0.bin_ms
-            fam["other"] += s1.other_ms - s0.other_ms
+            for k, f in (("k_bounce", "bounce"), ("k_bin", "bin")):
+                fam[k][0] += getattr(s1, f + "_ms") - getattr(s0, f + "_ms")
+                fam[k][1] += getattr(s1, f + "_bytes") - getattr(s0, f + "_bytes")
+                fam[k][2] += getattr(s1, f + "_launches") - getattr(s0, f + "_launches")
+            other_ms[0] += s1.other_ms - s0.other_ms
         else:
             scene.render(film, job)
 
@@ -195,18 +192,18 @@ def main():
     total_paths = paths_per_rank * world
     value = total_paths / elapsed / 1e6
 
-    # dominant kernel by device time (HIP events on the library's stream, profiled steps of this timed
-    # region): one instantiation of k_bounce, named as rocprofv3 shows it
-    dom = max(range(8), key=lambda c: per_class[c][0])
-    d_ms, d_bytes, d_launches, d_vertices = per_class[dom]
+    # the dominant kernel: k_bounce (every path vertex: shading, shadow ray, extension ray), timed with HIP
+    # events on the library's stream over the profiled steps of this timed region; named as rocprofv3 shows it
+    d_ms, d_bytes, d_launches = fam["k_bounce"]
     hs = host_scene.desc
     tris = "true" if hs.n_triangles > 0 else "false"
+
     def big(i):
         return i >= 0 and (hs.maps[i].width > 1 or hs.maps[i].height > 1)
     uv = "true" if any(big(m) for k in range(hs.n_materials)
                        for m in (hs.materials[k].albedo_map, hs.materials[k].emission_color_map, hs.materials[k].light_intensity_map,
                                  hs.materials[k].roughness_map, hs.materials[k].transparency_map)) else "false"
-    kernel = f"ptk::k_bounce<{dom}, {tris}, {uv}>"
+    kernel = f"ptk::k_bounce<{tris}, {uv}>"
     achieved = d_bytes / (d_ms * 1e-3) / 1e9 if d_ms > 0 else 0.0
     traffic = None
     traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -216,11 +213,13 @@ def main():
                 traffic = json.load(f).get(args.workload, {}).get(kernel)
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": kernel, "class": CLASS_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+    vertices_by_class = {CLASS_NAMES[c]: int(st.class_vertices[c]) for c in range(8) if st.class_vertices[c]}
+    roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_launch": d_bytes / max(d_launches, 1), "ms_per_launch": d_ms / max(d_launches, 1),
-                "vertices_per_launch": d_vertices / max(d_launches, 1), "launches": int(d_launches),
-                "profiled_steps": profiled["steps"], "device_ms": dict(fam)}
+                "launches": int(d_launches), "profiled_steps": profiled["steps"],
+                "device_ms": {"k_bounce": fam["k_bounce"][0], "k_bin": fam["k_bin"][0], "other": other_ms[0]},
+                "vertices_by_class": vertices_by_class}
 
     out = {
         "metric": "Mpaths/s (whole node) at 1080p, scenes/example + 1M-tri mesh, 1/2/4/8 GPUs",

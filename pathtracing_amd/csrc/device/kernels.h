@@ -6,21 +6,23 @@
 
 namespace ptk {
 
-// number of blocks k_bin_count / k_bin_scatter use for n records (= entries of a block_counts row used)
+// number of whole or partial BIN_CHUNK runs in n records
 uint32_t bin_blocks(uint32_t n);
 
 // In every launcher `bound` is an upper bound of the number of records, used only to size the grid;
 // the kernels read the true counts from device memory (*previous: the summary of the bounce that wrote
 // the pool they read; *info: the summary of the sorted list they produce or walk), so the host never
 // has to wait for a count before it queues the next bounce.
+// block_counts: [N_CLASSES][count_stride] per-chunk class counts; count_stride >= bin_blocks(capacity) + N_CLASSES
 void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathPool& pool, const SampleResults& res,
-                     BinInfo* first_info);
-// count + scan + scatter: class-sorted index list of the records of `pool`, summary in *info
+                     BinInfo* first_info, uint32_t* block_counts, uint32_t count_stride);
+// scan + scatter: class-sorted index list of the records of `pool` from the counts its writer left, summary in *info
 void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_t bound, const BinInfo* previous, uint32_t* block_counts,
                 uint32_t count_stride, BinInfo* info, uint32_t* list_out);
-// one vertex of every path of class `cls`; statistics: STATISTICS_SLOTS x N_STATISTICS per-block slots
-void launch_bounce(hipStream_t s, int cls, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in,
-                   const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info,
+// one vertex of every path; leaves the class counts of `out` in block_counts;
+// statistics: [N_CLASSES][STATISTICS_SLOTS][N_STATISTICS] per-class, per-block slots
+void launch_bounce(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
+                   const SampleResults& res, const uint32_t* list, const BinInfo* info, uint32_t* block_counts, uint32_t count_stride,
                    unsigned long long* statistics);
 void launch_sum_statistics(hipStream_t s, const unsigned long long* slots, unsigned long long* totals);
 void launch_accumulate(hipStream_t s, const BatchParams& b, const SampleResults& res, double* image, double* position, double* normal,

@@ -2,16 +2,15 @@
 //
 //   k_generate     camera samples, their first closest hit -> path records
 //                  (compute_pixel_color + Camera::make_ray + the first loop head of raytrace)
-//   k_bin_count    per-block counts of the records of each class
-//   k_bin_scan     exclusive scan of those counts
+//   k_bin_scan     exclusive scan of the per-chunk class counts the last kernel left
 //   k_bin_scatter  writes the class-sorted index list           (stable: record order is preserved)
-//   k_bounce<C>    one launch per material class over its segment of the list, one path vertex per
-//                  lane: emission with MIS, next-event sampling and the visibility march of that
+//   k_bounce       one path vertex per lane, a block works through chunks of one material class:
+//                  emission with MIS, next-event sampling and the visibility march of that
 //                  connection (sample_light + compute_visibility), BRDF sampling, medium switch,
 //                  Russian roulette (raytrace's loop body), then the free-flight distance and the
 //                  closest hit of the new ray (the next loop head + find_closest_hit); reads the
 //                  record through the list and writes the updated record, with the class of its
-//                  next vertex, to the other pool at the list position
+//                  next vertex, to the other pool at the list position; counts the classes it wrote
 //   k_accumulate   per-pixel sample means folded into the film  (compute_pixel_color's division and
 //                  increment_average)
 //
@@ -184,61 +183,39 @@ PTK_DEV Vertex next_vertex(const DevScene& sc, const BatchParams& b, const V3& o
 }
 
 // -------------------------------------------------------------------------------------------------
-template<bool TRIS>
-__global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, PathPool pool, SampleResults res, BinInfo* first_info) {
-    __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1];
-    TraversalStack st = make_stack(lds_stack);
-    if (blockIdx.x == 0 && threadIdx.x == 0) first_info->total = b.n_paths; // records in the first pool
-    for (uint32_t sid = blockIdx.x * BLOCK + threadIdx.x; sid < b.n_paths; sid += gridDim.x * BLOCK) {
-        uint32_t pixel, sample;
-        sample_coordinates(b, sid, pixel, sample);
-        Rng rng{rng_key(b.seed, pixel, sample), 0};
-        V3 org, dir;
-        camera_ray(sc, pixel, rng, org, dir);
-        surface_plane(res, 0)[sid] = make_double2(0.0, 0.0);
-        surface_plane(res, 1)[sid] = make_double2(0.0, 0.0);
-        surface_plane(res, 2)[sid] = make_double2(0.0, 0.0);
-        const uint32_t medium = static_cast<uint32_t>(sc.background_medium) & 0xFFFFu;
-        const Vertex v = next_vertex<TRIS>(sc, b, org, dir, medium, sid, rng.ctr, st);
-        if (v.cls < 0) { // color = throughput (1) * background_color
-            flush_color(res, sid, sc.background[0], sc.background[1], sc.background[2]);
-            pool.cls[sid] = CLASS_DONE;
-            continue;
-        }
-        st2(pool, PL_RAY0, sid, org.x, org.y);
-        st2(pool, PL_RAY1, sid, org.z, dir.x);
-        st2(pool, PL_RAY2, sid, dir.y, dir.z);
-        st2(pool, PL_THR0, sid, 1.0, 1.0);
-        st2(pool, PL_THR1, sid, 1.0, 0.0);
-        st2(pool, PL_SAV0, sid, 0.0, 0.0);
-        st2(pool, PL_SAV1, sid, 0.0, 0.0);
-        st2(pool, PL_COL, sid, 0.0, 0.0);
-        *reinterpret_cast<uint4*>(plane_ptr(pool, PL_HIT) + sid * 16u) =
-            make_uint4(static_cast<uint32_t>(__double2loint(v.t)), static_cast<uint32_t>(__double2hiint(v.t)),
-                       0u | (RAY_TRANSMITTED << TYPE_SHIFT) | (medium << 16), sid);
-        stu4(pool, PL_IDS, sid, rng.ctr, static_cast<uint32_t>(v.obj), static_cast<uint32_t>(v.prim), 0u);
-        pool.cls[sid] = static_cast<uint8_t>(v.cls);
+// Chunks.  The records of a pool lie class by class (the order the last bounce wrote them in); a
+// chunk is up to BIN_CHUNK consecutive records of one class.  Chunks are numbered class by class,
+// which is also the order of the records, and are the unit of work of k_bounce (one block works
+// through one chunk at a time) and of the class sort (block_counts has one entry per class and
+// chunk).
+struct ChunkTable {
+    uint32_t first_chunk[N_CLASSES + 1]; // chunks of class c: [first_chunk[c], first_chunk[c + 1])
+};
+PTK_DEV ChunkTable chunk_table(const BinInfo* info) {
+    ChunkTable t;
+    uint32_t running = 0;
+#pragma unroll
+    for (int c = 0; c < N_CLASSES; c++) {
+        t.first_chunk[c] = running;
+        running += (info->count[c] + BIN_CHUNK - 1) / BIN_CHUNK;
     }
+    t.first_chunk[N_CLASSES] = running;
+    return t;
+}
+// class, first record and number of records of a chunk
+PTK_DEV void locate_chunk(const BinInfo* info, const ChunkTable& t, uint32_t chunk, int& cls, uint32_t& first, uint32_t& count) {
+    cls = 0;
+#pragma unroll
+    for (int c = 1; c < N_CLASSES; c++)
+        if (chunk >= t.first_chunk[c]) cls = c;
+    const uint32_t offset = (chunk - t.first_chunk[cls]) * BIN_CHUNK;
+    first = info->start[cls] + offset;
+    count = min(static_cast<uint32_t>(BIN_CHUNK), info->count[cls] - offset);
 }
 
-// Per-block class counts of the records of `pool`: block b owns records [b * BIN_CHUNK,
-// (b + 1) * BIN_CHUNK) and leaves its counts in block_counts[class * count_stride + b].
-__global__ __launch_bounds__(BLOCK) void k_bin_count(PathPool pool, const BinInfo* previous, uint32_t* block_counts, uint32_t count_stride,
-                                                     uint32_t class_mask) {
-    const uint32_t n = previous->total;
-    if (blockIdx.x * BIN_CHUNK >= n) return;
-    __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
-    uint32_t my_counts[N_CLASSES];
-#pragma unroll
-    for (int c = 0; c < N_CLASSES; c++) my_counts[c] = 0;
-#pragma unroll
-    for (int r = 0; r < BIN_ROUNDS; r++) {
-        const uint32_t idx = blockIdx.x * BIN_CHUNK + r * BLOCK + threadIdx.x;
-        const int cls = idx < n ? pool.cls[idx] : 0xFF;
-#pragma unroll
-        for (int c = 0; c < N_CLASSES; c++)
-            if ((class_mask >> c) & 1u) my_counts[c] += static_cast<uint32_t>(__popcll(__ballot(cls == c)));
-    }
+// Per-class counts of the records a block wrote for one chunk -> block_counts[class][chunk].
+PTK_DEV void store_chunk_counts(uint32_t (*wave_counts)[N_CLASSES], const uint32_t* my_counts, uint32_t* block_counts,
+                                uint32_t count_stride, uint32_t chunk) {
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int c = 0; c < N_CLASSES; c++) wave_counts[threadIdx.x >> 6][c] = my_counts[c];
@@ -247,17 +224,79 @@ __global__ __launch_bounds__(BLOCK) void k_bin_count(PathPool pool, const BinInf
     if (threadIdx.x < N_CLASSES) {
         uint32_t total = 0;
         for (int w = 0; w < BLOCK / 64; w++) total += wave_counts[w][threadIdx.x];
-        block_counts[threadIdx.x * count_stride + blockIdx.x] = total;
+        block_counts[threadIdx.x * count_stride + chunk] = total;
+    }
+    __syncthreads(); // wave_counts is reused by the block's next chunk
+}
+
+// -------------------------------------------------------------------------------------------------
+// Camera samples and their first vertex.  The first pool holds the records in sample order as one
+// run (described to the class sort as class 0); chunk j = samples [j * BIN_CHUNK, (j + 1) * BIN_CHUNK).
+template<bool TRIS>
+__global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, PathPool pool, SampleResults res, BinInfo* first_info,
+                                                    uint32_t* block_counts, uint32_t count_stride) {
+    __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1];
+    __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
+    TraversalStack st = make_stack(lds_stack);
+    if (blockIdx.x == 0 && threadIdx.x < N_CLASSES) {
+        first_info->start[threadIdx.x] = threadIdx.x == 0 ? 0u : b.n_paths;
+        first_info->count[threadIdx.x] = threadIdx.x == 0 ? b.n_paths : 0u;
+        if (threadIdx.x == 0) first_info->total = b.n_paths;
+    }
+    const uint32_t n_chunks = (b.n_paths + BIN_CHUNK - 1) / BIN_CHUNK;
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        uint32_t my_counts[N_CLASSES];
+#pragma unroll
+        for (int c = 0; c < N_CLASSES; c++) my_counts[c] = 0;
+        for (int r = 0; r < BIN_ROUNDS; r++) {
+            const uint32_t sid = chunk * BIN_CHUNK + r * BLOCK + threadIdx.x;
+            int cls = -1;
+            if (sid < b.n_paths) {
+                uint32_t pixel, sample;
+                sample_coordinates(b, sid, pixel, sample);
+                Rng rng{rng_key(b.seed, pixel, sample), 0};
+                V3 org, dir;
+                camera_ray(sc, pixel, rng, org, dir);
+                surface_plane(res, 0)[sid] = make_double2(0.0, 0.0);
+                surface_plane(res, 1)[sid] = make_double2(0.0, 0.0);
+                surface_plane(res, 2)[sid] = make_double2(0.0, 0.0);
+                const uint32_t medium = static_cast<uint32_t>(sc.background_medium) & 0xFFFFu;
+                const Vertex v = next_vertex<TRIS>(sc, b, org, dir, medium, sid, rng.ctr, st);
+                cls = v.cls;
+                if (v.cls < 0) { // color = throughput (1) * background_color
+                    flush_color(res, sid, sc.background[0], sc.background[1], sc.background[2]);
+                    pool.cls[sid] = CLASS_DONE;
+                }
+                else {
+                    st2(pool, PL_RAY0, sid, org.x, org.y);
+                    st2(pool, PL_RAY1, sid, org.z, dir.x);
+                    st2(pool, PL_RAY2, sid, dir.y, dir.z);
+                    st2(pool, PL_THR0, sid, 1.0, 1.0);
+                    st2(pool, PL_THR1, sid, 1.0, 0.0);
+                    st2(pool, PL_SAV0, sid, 0.0, 0.0);
+                    st2(pool, PL_SAV1, sid, 0.0, 0.0);
+                    st2(pool, PL_COL, sid, 0.0, 0.0);
+                    stu4(pool, PL_HIT, sid, static_cast<uint32_t>(__double2loint(v.t)), static_cast<uint32_t>(__double2hiint(v.t)),
+                         0u | (RAY_TRANSMITTED << TYPE_SHIFT) | (medium << 16), sid);
+                    stu4(pool, PL_IDS, sid, rng.ctr, static_cast<uint32_t>(v.obj), static_cast<uint32_t>(v.prim), 0u);
+                    pool.cls[sid] = static_cast<uint8_t>(v.cls);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < N_CLASSES; c++)
+                if ((sc.class_mask >> c) & 1u) my_counts[c] += static_cast<uint32_t>(__popcll(__ballot(cls == c)));
+        }
+        store_chunk_counts(wave_counts, my_counts, block_counts, count_stride, chunk);
     }
 }
 
-// Exclusive scan, in class-major order, of block_counts[class * count_stride + block] for the first
-// n_blocks blocks of every class in class_mask; one workgroup.  Leaves the offsets in place and the
+// Exclusive scan, in class-major order, of block_counts[class * count_stride + chunk] over the
+// chunks of the pool `previous` describes, for every class in class_mask; one workgroup.  Leaves the offsets in place and the
 // per-class segment starts, counts and the total in `info`.  Tiles of 4096 counts: one uint4 per
 // thread, shuffles inside a wave, 16 wave sums through LDS, a running carry across tiles.
 __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* block_counts, uint32_t count_stride, uint32_t class_mask,
                                                    const BinInfo* previous, BinInfo* info) {
-    const uint32_t n_blocks = (previous->total + BIN_CHUNK - 1) / BIN_CHUNK;
+    const uint32_t n_blocks = chunk_table(previous).first_chunk[N_CLASSES];
     __shared__ uint32_t wave_sums[2][16];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t carry = 0; // the same in every thread
@@ -315,22 +354,26 @@ __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* block_counts, uint3
     if (threadIdx.x == 0) info->total = carry;
 }
 
-// Writes the class-sorted index list: record i of class c goes to block_offsets[c][block] + (number
-// of class-c records before it in the block).  Records of paths that ended are left out.
+// Writes the class-sorted index list: a record that continues with class c goes to
+// block_offsets[c][chunk] + (number of class-c records before it in its chunk).  Records of paths
+// that ended are left out.  One block per chunk of the pool `previous` describes.
 __global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathPool pool, const BinInfo* previous, const uint32_t* block_offsets,
                                                        uint32_t count_stride, uint32_t class_mask, uint32_t* list_out) {
-    const uint32_t n = previous->total;
-    if (blockIdx.x * BIN_CHUNK >= n) return;
+    const ChunkTable table = chunk_table(previous);
+    if (blockIdx.x >= table.first_chunk[N_CLASSES]) return;
+    int chunk_class;
+    uint32_t first, n;
+    locate_chunk(previous, table, blockIdx.x, chunk_class, first, n);
     __shared__ uint32_t counts[BIN_ROUNDS][BLOCK / 64][N_CLASSES];
     const int wave = threadIdx.x >> 6;
     int classes[BIN_ROUNDS];
     uint32_t below[BIN_ROUNDS];
 #pragma unroll
     for (int r = 0; r < BIN_ROUNDS; r++) {
-        const uint32_t idx = blockIdx.x * BIN_CHUNK + r * BLOCK + threadIdx.x;
+        const uint32_t i = r * BLOCK + threadIdx.x;
         int cls = -1;
-        if (idx < n) {
-            const uint8_t c = pool.cls[idx];
+        if (i < n) {
+            const uint8_t c = pool.cls[first + i];
             if (c < N_CLASSES) cls = c;
         }
         classes[r] = cls;
@@ -344,7 +387,7 @@ __global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathPool pool, const BinI
         }
     }
     __syncthreads();
-    // exclusive prefix over (round, wave) for each class, plus the block's global offset
+    // exclusive prefix over (round, wave) for each class, plus the chunk's global offset
     if (threadIdx.x < N_CLASSES && ((class_mask >> threadIdx.x) & 1u)) {
         uint32_t running = block_offsets[threadIdx.x * count_stride + blockIdx.x];
         for (int r = 0; r < BIN_ROUNDS; r++)
@@ -357,7 +400,7 @@ __global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathPool pool, const BinI
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < BIN_ROUNDS; r++)
-        if (classes[r] >= 0) list_out[counts[r][wave][classes[r]] + below[r]] = blockIdx.x * BIN_CHUNK + r * BLOCK + threadIdx.x;
+        if (classes[r] >= 0) list_out[counts[r][wave][classes[r]] + below[r]] = first + r * BLOCK + threadIdx.x;
 }
 
 struct Record { // the ten planes of one path record
@@ -380,232 +423,306 @@ PTK_DEV Record load_record(const PathPool& p, uint32_t i) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// One vertex of every path whose current vertex has class CLS: the loop body of raytrace
-// (app/pathtracer.cpp:69-171) followed by the head of its next iteration (:53-67).  Reads record
-// list[first + j] of `in`, writes record first + j of `out`.
+// A path vertex while it is being shaded.
+struct PathVertex {
+    V3 point, dir; // the vertex, and the direction the path arrived along
+    double t;      // distance travelled to it
+    int obj, prim;
+    uint32_t sid, depth, medium;
+    V3 thr, saved, color;
+    double scatter_pdf;
+    uint32_t ray_type;
+    bool has_hit;
+    Rng rng;
+    // results of shading: the new direction and medium, and the connection to a light, if any
+    V3 n_dir;
+    int next_medium;
+    bool connect;
+    int light_index;
+    V3 sh_dir, sh_contrib;
+    double sh_dist;
+    uint64_t sh_key;
+};
+
+// Loop body of raytrace (app/pathtracer.cpp:69-155) for a vertex of class CLS: emission with MIS,
+// next-event sampling up to the visibility march, BRDF sampling, medium switch.
+template<int CLS, bool TRIS, bool UV>
+PTK_DEV void shade_vertex(const DevScene& sc, const SampleResults& res, const DevMedium& med, PathVertex& v) {
+    V3& color = v.color;
+    V3& thr = v.thr;
+    V3& saved = v.saved;
+    double& scatter_pdf = v.scatter_pdf;
+    uint32_t& ray_type = v.ray_type;
+    bool& has_hit = v.has_hit;
+    Rng& rng = v.rng;
+    V3& n_dir = v.n_dir;
+    int& next_medium = v.next_medium;
+    bool& connect = v.connect;
+    int& light_index = v.light_index;
+    V3& sh_dir = v.sh_dir;
+    V3& sh_contrib = v.sh_contrib;
+    double& sh_dist = v.sh_dist;
+    uint64_t& sh_key = v.sh_key;
+    const V3 point = v.point, dir = v.dir;
+    const double t = v.t;
+    const uint32_t depth = v.depth, medium = v.medium, sid = v.sid;
+    if (CLS == CLASS_SCATTER) {
+        // :71-93
+        color = color + medium_emission(med) * thr;
+        thr = thr * medium_sample_weight(med, t, true);
+        n_dir = sample_spherical(rng);
+        if (sc.nee) {
+            LightSample ls;
+            if (pick_light_point<TRIS>(sc, -1, point, ls, rng)) {
+                double weight = mis_weight(ls.light_pdf, PHASE_ISOTROPIC);
+                sh_contrib = thr * (weight * PHASE_ISOTROPIC / ls.light_pdf * static_cast<double>(sc.n_lights));
+                sh_dir = ls.direction;
+                sh_dist = ls.distance;
+                sh_key = rng_fork(rng.key, rng.ctr);
+                rng.ctr++;
+                light_index = ls.light_index;
+                connect = true;
+            }
+            ray_type = RAY_DIFFUSE;
+            scatter_pdf = PHASE_ISOTROPIC;
+            saved = point;
+        }
+    }
+    else {
+        // :94-155
+        thr = thr * medium_sample_weight(med, t, false);
+        const int obj = v.obj;
+        const int prim = v.prim;
+        const DevObject& o = sc.objects[obj];
+        const DevMaterial& m = o.mat;
+        Surface s;
+        s.point = point;
+        s.incident = dir;
+        s.obj = obj;
+        s.prim = prim;
+        V3 normal = object_normal<TRIS>(sc, o, point, prim);
+        s.outside = dot(dir, normal) < 0;
+        s.normal = s.outside ? normal : -normal;
+        s.use_uv = UV && m.needs_uv != 0;
+        s.u = s.v = 0;
+        if (s.use_uv) object_uv<TRIS>(sc, o, point, prim, s.u, s.v);
+
+        if (!has_hit) {
+            surface_plane(res, 0)[sid] = make_double2(point.x, point.y);
+            surface_plane(res, 1)[sid] = make_double2(point.z, s.normal.x);
+            surface_plane(res, 2)[sid] = make_double2(s.normal.y, s.normal.z);
+            has_hit = true;
+        }
+        const bool is_specular = ray_type == RAY_REFLECTED || ray_type == RAY_TRANSMITTED;
+        if (m.is_light) { // :106-119
+            double weight = 1;
+            if (sc.nee && depth != 0 && !is_specular)
+                weight = mis_weight(scatter_pdf, object_light_pdf<TRIS>(sc, o, point, saved, prim));
+            color = color + material_emittance(sc, m, s.use_uv, s.u, s.v) * weight * thr;
+        }
+        if (sc.nee) { // sample_light up to the march (src/objects.cpp:515-551, 562-578)
+            LightSample ls;
+            if (pick_light_point<TRIS>(sc, obj, point, ls, rng)) {
+                V3 brdf = material_eval<CLS>(sc, m, s, ls.direction, rng);
+                if (len2(brdf) != 0) {
+                    double pdf = material_pdf<CLS>(sc, m, s, ls.direction);
+                    const uint64_t key = rng_fork(rng.key, rng.ctr);
+                    rng.ctr++;
+                    bool wrong_side = dot(s.incident, s.normal) * dot(ls.direction, s.normal) > 0;
+                    double cosine = fmax(dot(s.normal, ls.direction), 0.0);
+                    if (!wrong_side && cosine > 0) {
+                        double weight = mis_weight(ls.light_pdf, pdf);
+                        sh_contrib = brdf * thr * (weight * cosine / ls.light_pdf * static_cast<double>(sc.n_lights));
+                        sh_dir = ls.direction;
+                        sh_dist = ls.distance;
+                        sh_key = key;
+                        light_index = ls.light_index;
+                        connect = true;
+                    }
+                }
+            }
+        }
+        BrdfSample bs = material_sample<CLS>(sc, m, s, rng); // :126-137
+        bool is_virtual = allow_direct_light(sc, m, s, rng);
+        if (is_virtual) {
+            bs.type = ray_type;
+        }
+        else {
+            scatter_pdf = bs.pdf;
+            saved = point;
+        }
+        thr = thr * bs.weight;
+        if (dot(s.incident, s.normal) * dot(bs.outgoing, s.normal) > 0) // :139-151
+            next_medium = s.outside ? m.internal_medium : m.external_medium;
+        n_dir = bs.outgoing;
+        ray_type = bs.type;
+    }
+}
+
+// One vertex of every path: the loop body of raytrace (app/pathtracer.cpp:69-171) followed by the
+// head of its next iteration (:53-67).  A block works through chunks of the class-sorted list (every
+// chunk is of one class, so the class switch below is a scalar branch); for chunk records
+// [first, first + n) it reads record list[first + j] of `in` and writes record first + j of `out`,
+// and leaves the counts of the classes it wrote in block_counts[class][chunk].
 // TRIS: the scene has triangles or meshes; UV: some material reads a map larger than 1x1 (texture
 // coordinates are needed).  Scenes without them get kernels without that code and its registers.
-template<int CLS, bool TRIS, bool UV>
+// statistics: per class and block [class][STATISTICS_SLOTS][N_STATISTICS].
+template<bool TRIS, bool UV>
 __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_bounce(DevScene sc, BatchParams b, PathPool in, PathPool out,
                                                                                       SampleResults res, const uint32_t* list,
-                                                                                      const BinInfo* info, unsigned long long* statistics) {
+                                                                                      const BinInfo* info, uint32_t* block_counts,
+                                                                                      uint32_t count_stride,
+                                                                                      unsigned long long* statistics) {
     __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1];
     __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
+    __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
     TraversalStack st = make_stack(lds_stack);
-    const uint32_t n = info->count[CLS];
-    const uint32_t first = info->start[CLS];
-    uint32_t stat[N_STATISTICS] = {};
+    const ChunkTable table = chunk_table(info);
 #ifdef PTK_STAMPS
-#define PTK_STAMP(k)                                                        \
-    {                                                                       \
-        const uint64_t now_ = __builtin_readcyclecounter();                 \
-        if ((threadIdx.x & 63) == 0) stat[4 + (k)] += static_cast<uint32_t>((now_ - stamp_) >> 4); \
-        stamp_ = now_;                                                      \
+#define PTK_STAMP(k)                                                                                   \
+    {                                                                                                  \
+        const uint64_t now_ = __builtin_readcyclecounter();                                            \
+        if ((threadIdx.x & 63) == 0) stat[4 + (k)] += static_cast<uint32_t>((now_ - stamp_) >> 4);     \
+        stamp_ = now_;                                                                                 \
     }
     uint64_t stamp_ = __builtin_readcyclecounter();
 #else
 #define PTK_STAMP(k)
 #endif
-    if (blockIdx.x * BLOCK >= n) return;
-    // Software pipeline over the grid-stride loop: the record of the next iteration is requested in
-    // the middle of the current one (after the table lookups of shading, before the two ray casts),
-    // and its list entry one iteration earlier still, so neither latency is paid at the loop top.
-    const uint32_t stride = gridDim.x * BLOCK;
-    uint32_t qi = blockIdx.x * BLOCK + threadIdx.x;
-    bool have = qi < n;
-    Record cur{};
-    if (have) cur = load_record(in, list[first + qi]);
-    uint32_t src_next = qi + stride < n ? list[first + qi + stride] : 0u;
-    for (; have; qi += stride) {
-        const uint32_t dst = first + qi;
-        const bool have_next = qi + stride < n;
-        const double2 r0 = cur.r0, r1 = cur.r1, r2 = cur.r2, t0 = cur.t0, t1 = cur.t1, v0 = cur.v0, v1 = cur.v1, cc = cur.cc;
-        const uint4 hit = cur.hit, ids = cur.ids;
-        V3 org = v3(r0.x, r0.y, r1.x);
-        V3 dir = v3(r1.y, r2.x, r2.y);
-        V3 thr = v3(t0.x, t0.y, t1.x);
-        V3 saved = v3(v0.x, v0.y, v1.x);
-        V3 color = v3(v1.y, cc.x, cc.y);
-        double scatter_pdf = t1.y;
-        const uint32_t flags = hit.z;
-        const uint32_t sid = hit.w;
-        const uint32_t depth = flags & DEPTH_MASK;
-        uint32_t ray_type = (flags >> TYPE_SHIFT) & 3u;
-        bool has_hit = (flags & FLAG_HAS_HIT) != 0;
-        uint32_t medium = flags >> 16;
-        if (medium == MEDIUM_NONE) medium = static_cast<uint32_t>(sc.background_medium);
-        const DevMedium& med = sc.media[medium];
-        uint32_t pixel, sample;
-        sample_coordinates(b, sid, pixel, sample);
-        Rng rng{rng_key(b.seed, pixel, sample), ids.x};
-        if (med.type == PTK_MEDIUM_HOMOGENEOUS_SCATTERING) {
-            // the numbers drawn for the free-flight distance when this vertex was found: the
-            // channel, and the distance only when that channel attenuates (src/medium.cpp:45-51)
-            int channel = rng.integer(0, 3);
-            if (med.extinction[channel] != 0) rng.ctr++;
-        }
-        const double t = __hiloint2double(static_cast<int>(hit.y), static_cast<int>(hit.x));
-        const V3 point = org + dir * t;
-        int next_medium = static_cast<int>(medium);
-        V3 n_dir;
-        bool connect = false;
-        int light_index = 0;
-        V3 sh_dir = v3(0.0), sh_contrib = v3(0.0);
-        double sh_dist = 0;
-        uint64_t sh_key = 0;
-
-        if (CLS == CLASS_SCATTER) {
-            // :71-93
-            color = color + medium_emission(med) * thr;
-            thr = thr * medium_sample_weight(med, t, true);
-            n_dir = sample_spherical(rng);
-            if (sc.nee) {
-                LightSample ls;
-                if (pick_light_point<TRIS>(sc, -1, point, ls, rng)) {
-                    double weight = mis_weight(ls.light_pdf, PHASE_ISOTROPIC);
-                    sh_contrib = thr * (weight * PHASE_ISOTROPIC / ls.light_pdf * static_cast<double>(sc.n_lights));
-                    sh_dir = ls.direction;
-                    sh_dist = ls.distance;
-                    sh_key = rng_fork(rng.key, rng.ctr);
-                    rng.ctr++;
-                    light_index = ls.light_index;
-                    connect = true;
+    for (uint32_t chunk = blockIdx.x; chunk < table.first_chunk[N_CLASSES]; chunk += gridDim.x) {
+        int cls;
+        uint32_t first, n;
+        locate_chunk(info, table, chunk, cls, first, n);
+        uint32_t stat[N_STATISTICS] = {};
+        uint32_t my_counts[N_CLASSES];
+#pragma unroll
+        for (int c = 0; c < N_CLASSES; c++) my_counts[c] = 0;
+        // Software pipeline over the rounds of the chunk: the record of the next round is requested
+        // in the middle of the current one (after the table lookups of shading, before the two ray
+        // casts), and its list entry one round earlier still, so neither latency is paid at the top.
+        uint32_t qi = threadIdx.x;
+        Record cur{};
+        if (qi < n) cur = load_record(in, list[first + qi]);
+        uint32_t src_next = qi + BLOCK < n ? list[first + qi + BLOCK] : 0u;
+        for (int r = 0; r < BIN_ROUNDS && r * BLOCK < n; r++, qi += BLOCK) {
+            const bool have = qi < n, have_next = qi + BLOCK < n;
+            const uint32_t dst = first + qi;
+            int new_cls = -1;
+            Record nxt{};
+            uint32_t src_after = 0;
+            if (have) {
+                PathVertex v;
+                const V3 org = v3(cur.r0.x, cur.r0.y, cur.r1.x);
+                v.dir = v3(cur.r1.y, cur.r2.x, cur.r2.y);
+                v.thr = v3(cur.t0.x, cur.t0.y, cur.t1.x);
+                v.saved = v3(cur.v0.x, cur.v0.y, cur.v1.x);
+                v.color = v3(cur.v1.y, cur.cc.x, cur.cc.y);
+                v.scatter_pdf = cur.t1.y;
+                const uint32_t flags = cur.hit.z;
+                v.sid = cur.hit.w;
+                v.depth = flags & DEPTH_MASK;
+                v.ray_type = (flags >> TYPE_SHIFT) & 3u;
+                v.has_hit = (flags & FLAG_HAS_HIT) != 0;
+                v.medium = flags >> 16;
+                if (v.medium == MEDIUM_NONE) v.medium = static_cast<uint32_t>(sc.background_medium);
+                const DevMedium& med = sc.media[v.medium];
+                uint32_t pixel, sample;
+                sample_coordinates(b, v.sid, pixel, sample);
+                v.rng = Rng{rng_key(b.seed, pixel, sample), cur.ids.x};
+                if (med.type == PTK_MEDIUM_HOMOGENEOUS_SCATTERING) {
+                    // the numbers drawn for the free-flight distance when this vertex was found: the
+                    // channel, and the distance only when that channel attenuates (src/medium.cpp:45-51)
+                    int channel = v.rng.integer(0, 3);
+                    if (med.extinction[channel] != 0) v.rng.ctr++;
                 }
-                ray_type = RAY_DIFFUSE;
-                scatter_pdf = PHASE_ISOTROPIC;
-                saved = point;
-            }
-        }
-        else {
-            // :94-155
-            thr = thr * medium_sample_weight(med, t, false);
-            const int obj = static_cast<int>(ids.y);
-            const int prim = static_cast<int>(ids.z);
-            const DevObject& o = sc.objects[obj];
-            const DevMaterial& m = o.mat;
-            Surface s;
-            s.point = point;
-            s.incident = dir;
-            s.obj = obj;
-            s.prim = prim;
-            V3 normal = object_normal<TRIS>(sc, o, point, prim);
-            s.outside = dot(dir, normal) < 0;
-            s.normal = s.outside ? normal : -normal;
-            s.use_uv = UV && m.needs_uv != 0;
-            s.u = s.v = 0;
-            if (s.use_uv) object_uv<TRIS>(sc, o, point, prim, s.u, s.v);
+                v.t = __hiloint2double(static_cast<int>(cur.hit.y), static_cast<int>(cur.hit.x));
+                v.point = org + v.dir * v.t;
+                v.obj = static_cast<int>(cur.ids.y);
+                v.prim = static_cast<int>(cur.ids.z);
+                v.next_medium = static_cast<int>(v.medium);
+                v.connect = false;
+                v.light_index = 0;
+                v.sh_dir = v3(0.0);
+                v.sh_contrib = v3(0.0);
+                v.sh_dist = 0;
+                v.sh_key = 0;
+                switch (cls) { // uniform over the block
+                    case 0: shade_vertex<0, TRIS, UV>(sc, res, med, v); break;
+                    case 1: shade_vertex<1, TRIS, UV>(sc, res, med, v); break;
+                    case 2: shade_vertex<2, TRIS, UV>(sc, res, med, v); break;
+                    case 3: shade_vertex<3, TRIS, UV>(sc, res, med, v); break;
+                    case 4: shade_vertex<4, TRIS, UV>(sc, res, med, v); break;
+                    case 5: shade_vertex<5, TRIS, UV>(sc, res, med, v); break;
+                    case 6: shade_vertex<6, TRIS, UV>(sc, res, med, v); break;
+                    default: shade_vertex<CLASS_SCATTER, TRIS, UV>(sc, res, med, v); break;
+                }
 
-            if (!has_hit) {
-                surface_plane(res, 0)[sid] = make_double2(point.x, point.y);
-                surface_plane(res, 1)[sid] = make_double2(point.z, s.normal.x);
-                surface_plane(res, 2)[sid] = make_double2(s.normal.y, s.normal.z);
-                has_hit = true;
-            }
-            const bool is_specular = ray_type == RAY_REFLECTED || ray_type == RAY_TRANSMITTED;
-            if (m.is_light) { // :106-119
-                double weight = 1;
-                if (sc.nee && depth != 0 && !is_specular)
-                    weight = mis_weight(scatter_pdf, object_light_pdf<TRIS>(sc, o, point, saved, prim));
-                color = color + material_emittance(sc, m, s.use_uv, s.u, s.v) * weight * thr;
-            }
-            if (sc.nee) { // sample_light up to the march (src/objects.cpp:515-551, 562-578)
-                LightSample ls;
-                if (pick_light_point<TRIS>(sc, obj, point, ls, rng)) {
-                    V3 brdf = material_eval<CLS>(sc, m, s, ls.direction, rng);
-                    if (len2(brdf) != 0) {
-                        double pdf = material_pdf<CLS>(sc, m, s, ls.direction);
-                        const uint64_t key = rng_fork(rng.key, rng.ctr);
-                        rng.ctr++;
-                        bool wrong_side = dot(s.incident, s.normal) * dot(ls.direction, s.normal) > 0;
-                        double cosine = fmax(dot(s.normal, ls.direction), 0.0);
-                        if (!wrong_side && cosine > 0) {
-                            double weight = mis_weight(ls.light_pdf, pdf);
-                            sh_contrib = brdf * thr * (weight * cosine / ls.light_pdf * static_cast<double>(sc.n_lights));
-                            sh_dir = ls.direction;
-                            sh_dist = ls.distance;
-                            sh_key = key;
-                            light_index = ls.light_index;
-                            connect = true;
-                        }
-                    }
+                // Russian roulette :157-171
+                bool allow = true;
+                if (static_cast<int>(v.depth) >= sc.min_depth) {
+                    double threshold = fmin(vmax(v.thr), 0.9);
+                    allow = v.rng.u01() < threshold;
+                    if (allow) v.thr = v.thr / threshold;
+                }
+                const bool alive = allow && static_cast<int>(v.depth) + 1 <= sc.max_depth;
+                PTK_STAMP(0)
+
+                // request the next round's record and the list entry of the one after
+                if (have_next) nxt = load_record(in, src_next);
+                if (qi + 2 * BLOCK < n) src_after = list[first + qi + 2 * BLOCK];
+
+                // the connection: compute_visibility (src/objects.cpp:470-513) and the acceptance test
+                // of sample_light (:558), on its own forked random-number stream
+                if (v.connect) {
+                    Rng march_rng{v.sh_key, 0};
+                    stat[2]++;
+                    V3 visible = march_to_light<TRIS, UV>(sc, v.point, v.sh_dir, static_cast<int>(v.medium), v.light_index, v.sh_dist,
+                                                          march_rng, st, stat[0]);
+                    v.color = v.color + v.sh_contrib * visible;
+                }
+                PTK_STAMP(1)
+
+                // the head of the next loop iteration: where does the new ray end
+                Vertex nv;
+                nv.cls = -1;
+                const uint32_t medium_bits = v.next_medium < 0 ? MEDIUM_NONE : static_cast<uint32_t>(v.next_medium);
+                if (alive) {
+                    stat[1]++;
+                    nv = next_vertex<TRIS>(sc, b, v.point, v.n_dir, medium_bits, v.sid, v.rng.ctr, st);
+                    if (nv.cls < 0 && !sc.background_is_black) v.color = v.color + v.thr * v3(sc.background);
+                }
+                PTK_STAMP(2)
+                new_cls = nv.cls;
+                if (nv.cls < 0) { // the path ended here
+                    flush_color(res, v.sid, v.color.x, v.color.y, v.color.z);
+                    out.cls[dst] = CLASS_DONE;
+                }
+                else {
+                    stat[3]++;
+                    st2(out, PL_RAY0, dst, v.point.x, v.point.y);
+                    st2(out, PL_RAY1, dst, v.point.z, v.n_dir.x);
+                    st2(out, PL_RAY2, dst, v.n_dir.y, v.n_dir.z);
+                    st2(out, PL_THR0, dst, v.thr.x, v.thr.y);
+                    st2(out, PL_THR1, dst, v.thr.z, v.scatter_pdf);
+                    st2(out, PL_SAV0, dst, v.saved.x, v.saved.y);
+                    st2(out, PL_SAV1, dst, v.saved.z, v.color.x);
+                    st2(out, PL_COL, dst, v.color.y, v.color.z);
+                    stu4(out, PL_HIT, dst, static_cast<uint32_t>(__double2loint(nv.t)), static_cast<uint32_t>(__double2hiint(nv.t)),
+                         (v.depth + 1) | (v.ray_type << TYPE_SHIFT) | (v.has_hit ? FLAG_HAS_HIT : 0u) | (medium_bits << 16), v.sid);
+                    stu4(out, PL_IDS, dst, v.rng.ctr, static_cast<uint32_t>(nv.obj), static_cast<uint32_t>(nv.prim), 0u);
+                    out.cls[dst] = static_cast<uint8_t>(nv.cls);
                 }
             }
-            BrdfSample bs = material_sample<CLS>(sc, m, s, rng); // :126-137
-            bool is_virtual = allow_direct_light(sc, m, s, rng);
-            if (is_virtual) {
-                bs.type = ray_type;
-            }
-            else {
-                scatter_pdf = bs.pdf;
-                saved = point;
-            }
-            thr = thr * bs.weight;
-            if (dot(s.incident, s.normal) * dot(bs.outgoing, s.normal) > 0) // :139-151
-                next_medium = s.outside ? m.internal_medium : m.external_medium;
-            n_dir = bs.outgoing;
-            ray_type = bs.type;
+#pragma unroll
+            for (int c = 0; c < N_CLASSES; c++)
+                if ((sc.class_mask >> c) & 1u) my_counts[c] += static_cast<uint32_t>(__popcll(__ballot(new_cls == c)));
+            cur = nxt;
+            src_next = src_after;
+            PTK_STAMP(3)
         }
-
-        // Russian roulette :157-171
-        bool allow = true;
-        if (static_cast<int>(depth) >= sc.min_depth) {
-            double threshold = fmin(vmax(thr), 0.9);
-            allow = rng.u01() < threshold;
-            if (allow) thr = thr / threshold;
-        }
-        const bool alive = allow && static_cast<int>(depth) + 1 <= sc.max_depth;
-
-        PTK_STAMP(0)
-        // request the next iteration's record and the list entry of the one after
-        Record nxt{};
-        if (have_next) nxt = load_record(in, src_next);
-        const uint32_t src_after = qi + 2 * stride < n ? list[first + qi + 2 * stride] : 0u;
-
-        // the connection: compute_visibility (src/objects.cpp:470-513) and the acceptance test of
-        // sample_light (:558), on its own forked random-number stream
-        if (connect) {
-            Rng march_rng{sh_key, 0};
-            stat[2]++;
-            V3 visible = march_to_light<TRIS, UV>(sc, point, sh_dir, static_cast<int>(medium), light_index, sh_dist, march_rng, st, stat[0]);
-            color = color + sh_contrib * visible;
-        }
-
-        PTK_STAMP(1)
-        // the head of the next loop iteration: where does the new ray end
-        Vertex nv;
-        nv.cls = -1;
-        const uint32_t medium_bits = next_medium < 0 ? MEDIUM_NONE : static_cast<uint32_t>(next_medium);
-        if (alive) {
-            stat[1]++;
-            nv = next_vertex<TRIS>(sc, b, point, n_dir, medium_bits, sid, rng.ctr, st);
-            if (nv.cls < 0 && !sc.background_is_black) color = color + thr * v3(sc.background);
-        }
-        PTK_STAMP(2)
-        if (nv.cls < 0) { // the path ended here
-            flush_color(res, sid, color.x, color.y, color.z);
-            out.cls[dst] = CLASS_DONE;
-        }
-        else {
-        stat[3]++;
-        st2(out, PL_RAY0, dst, point.x, point.y);
-        st2(out, PL_RAY1, dst, point.z, n_dir.x);
-        st2(out, PL_RAY2, dst, n_dir.y, n_dir.z);
-        st2(out, PL_THR0, dst, thr.x, thr.y);
-        st2(out, PL_THR1, dst, thr.z, scatter_pdf);
-        st2(out, PL_SAV0, dst, saved.x, saved.y);
-        st2(out, PL_SAV1, dst, saved.z, color.x);
-        st2(out, PL_COL, dst, color.y, color.z);
-        stu4(out, PL_HIT, dst, static_cast<uint32_t>(__double2loint(nv.t)), static_cast<uint32_t>(__double2hiint(nv.t)),
-             (depth + 1) | (ray_type << TYPE_SHIFT) | (has_hit ? FLAG_HAS_HIT : 0u) | (medium_bits << 16), sid);
-        stu4(out, PL_IDS, dst, rng.ctr, static_cast<uint32_t>(nv.obj), static_cast<uint32_t>(nv.prim), 0u);
-        out.cls[dst] = static_cast<uint8_t>(nv.cls);
-        }
-        cur = nxt;
-        src_next = src_after;
-        have = have_next;
-        PTK_STAMP(3)
+        store_chunk_counts(wave_counts, my_counts, block_counts, count_stride, chunk);
+        add_block_statistics(statistics + static_cast<size_t>(cls) * N_STATISTICS * STATISTICS_SLOTS, wave_sums, stat);
     }
-    add_block_statistics(statistics, wave_sums, stat);
 }
 
 // Sums the per-block statistics slots into totals[N_STATISTICS]; one block.
@@ -733,27 +850,31 @@ uint32_t bin_blocks(uint32_t n) {
     return n == 0 ? 1u : (n + BIN_CHUNK - 1) / BIN_CHUNK;
 }
 
+// blocks for a pool of at most `bound` records: its chunks (each class may end in a partial one)
+static inline uint32_t chunk_blocks(uint32_t bound) {
+    return bin_blocks(bound) + N_CLASSES;
+}
+
 void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathPool& pool, const SampleResults& res,
-                     BinInfo* first_info) {
-    const dim3 grid(grid_for(b.n_paths, 8192)), block(BLOCK);
-    if (sc.has_triangles) hipLaunchKernelGGL(k_generate<true>, grid, block, 0, s, sc, b, pool, res, first_info);
-    else hipLaunchKernelGGL(k_generate<false>, grid, block, 0, s, sc, b, pool, res, first_info);
+                     BinInfo* first_info, uint32_t* block_counts, uint32_t count_stride) {
+    const dim3 grid(min(bin_blocks(b.n_paths), static_cast<uint32_t>(STATISTICS_SLOTS))), block(BLOCK);
+    if (sc.has_triangles) hipLaunchKernelGGL(k_generate<true>, grid, block, 0, s, sc, b, pool, res, first_info, block_counts, count_stride);
+    else hipLaunchKernelGGL(k_generate<false>, grid, block, 0, s, sc, b, pool, res, first_info, block_counts, count_stride);
 }
 
 void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_t bound, const BinInfo* previous, uint32_t* block_counts,
                 uint32_t count_stride, BinInfo* info, uint32_t* list_out) {
-    const dim3 grid(bin_blocks(bound)), block(BLOCK);
-    hipLaunchKernelGGL(k_bin_count, grid, block, 0, s, pool, previous, block_counts, count_stride, sc.class_mask);
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, block_counts, count_stride, sc.class_mask, previous, info);
-    hipLaunchKernelGGL(k_bin_scatter, grid, block, 0, s, pool, previous, block_counts, count_stride, sc.class_mask, list_out);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(chunk_blocks(bound)), dim3(BLOCK), 0, s, pool, previous, block_counts, count_stride,
+                       sc.class_mask, list_out);
 }
 
-template<int CLS>
-static void launch_bounce_t(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in,
-                            const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info,
-                            unsigned long long* statistics) {
-    const dim3 grid(grid_for(bound, STATISTICS_SLOTS)), block(BLOCK);
-#define PTK_LAUNCH_BOUNCE(T, U) hipLaunchKernelGGL((k_bounce<CLS, T, U>), grid, block, 0, s, sc, b, in, out, res, list, info, statistics)
+void launch_bounce(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
+                   const SampleResults& res, const uint32_t* list, const BinInfo* info, uint32_t* block_counts, uint32_t count_stride,
+                   unsigned long long* statistics) {
+    const dim3 grid(min(chunk_blocks(bound), static_cast<uint32_t>(STATISTICS_SLOTS))), block(BLOCK);
+#define PTK_LAUNCH_BOUNCE(T, U) \
+    hipLaunchKernelGGL((k_bounce<T, U>), grid, block, 0, s, sc, b, in, out, res, list, info, block_counts, count_stride, statistics)
     if (sc.has_triangles) {
         if (sc.needs_uv) PTK_LAUNCH_BOUNCE(true, true);
         else PTK_LAUNCH_BOUNCE(true, false);
@@ -763,22 +884,6 @@ static void launch_bounce_t(hipStream_t s, uint32_t bound, const DevScene& sc, c
         else PTK_LAUNCH_BOUNCE(false, false);
     }
 #undef PTK_LAUNCH_BOUNCE
-}
-
-void launch_bounce(hipStream_t s, int cls, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in,
-                   const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info,
-                   unsigned long long* statistics) {
-    switch (cls) {
-        case 0: launch_bounce_t<0>(s, bound, sc, b, in, out, res, list, info, statistics); break;
-        case 1: launch_bounce_t<1>(s, bound, sc, b, in, out, res, list, info, statistics); break;
-        case 2: launch_bounce_t<2>(s, bound, sc, b, in, out, res, list, info, statistics); break;
-        case 3: launch_bounce_t<3>(s, bound, sc, b, in, out, res, list, info, statistics); break;
-        case 4: launch_bounce_t<4>(s, bound, sc, b, in, out, res, list, info, statistics); break;
-        case 5: launch_bounce_t<5>(s, bound, sc, b, in, out, res, list, info, statistics); break;
-        case 6: launch_bounce_t<6>(s, bound, sc, b, in, out, res, list, info, statistics); break;
-        case 7: launch_bounce_t<7>(s, bound, sc, b, in, out, res, list, info, statistics); break;
-        default: break;
-    }
 }
 
 void launch_sum_statistics(hipStream_t s, const unsigned long long* slots, unsigned long long* totals) {

@@ -197,7 +197,7 @@ int ensure_capacity(PtkScene* s, int64_t paths) {
     s->results.plane_doubles = n * 2;
     HIP_TRY(b.alloc(&s->results.surface, n * 6));
     HIP_TRY(b.alloc(&s->list, n));
-    s->count_stride = (bin_blocks(static_cast<uint32_t>(n)) + 3u) & ~3u; // rows stay 16-byte aligned
+    s->count_stride = (bin_blocks(static_cast<uint32_t>(n)) + N_CLASSES + 3u) & ~3u; // one entry per chunk; rows stay 16-byte aligned
     HIP_TRY(b.alloc(&s->block_counts, static_cast<size_t>(s->count_stride) * N_CLASSES));
     s->capacity = paths;
     return PTK_OK;
@@ -210,7 +210,7 @@ constexpr uint64_t BOUNCE_BYTES_PER_VERTEX = 4 + RECORD_BYTES;      // list entr
 constexpr uint64_t BOUNCE_BYTES_PER_CONTINUED = RECORD_BYTES + 1;   // record, class out
 constexpr uint64_t BOUNCE_BYTES_PER_ENDED = 32 + 1;                 // radiance flushed to the results, class out
 constexpr uint64_t BOUNCE_BYTES_PER_PATH = 3 * 16;                  // first-surface position and normal, once
-constexpr uint64_t BIN_BYTES_PER_RECORD = 2;                        // class in, twice (count, scatter)
+constexpr uint64_t BIN_BYTES_PER_RECORD = 1;                        // class in
 constexpr uint64_t BIN_BYTES_PER_VERTEX = 4;                        // list entry out
 constexpr uint64_t GENERATE_BYTES_PER_PATH = RECORD_BYTES + 1 + 3 * 16; // record, class, zeroed surface results out
 constexpr uint64_t ACCUMULATE_BYTES_PER_PATH = 32 + 3 * 16;         // results in
@@ -251,10 +251,6 @@ struct EventTimer {
             switch (sp.first) {
                 case 0: s->stats.bounce_ms += ms; break;
                 case 1: s->stats.bin_ms += ms; break;
-                case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15:
-                    s->stats.class_ms[sp.first - 8] += ms;
-                    s->stats.bounce_ms += ms;
-                    break;
                 default: s->stats.other_ms += ms; break;
             }
         }
@@ -274,7 +270,7 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
     PtkStats& st = s->stats;
     HIP_TRY(hipMemsetAsync(s->d_statistics, 0, STATISTICS_BYTES, g_stream));
     timer.begin(2);
-    launch_generate(g_stream, s->dev, b, s->pools[0], s->results, &s->d_info[1]);
+    launch_generate(g_stream, s->dev, b, s->pools[0], s->results, &s->d_info[1], s->block_counts, s->count_stride);
     timer.end();
     st.paths += b.n_paths;
     st.algorithmic_bytes += GENERATE_BYTES_PER_PATH * b.n_paths;
@@ -316,20 +312,17 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
         timer.begin(1);
         launch_bin(g_stream, s->dev, current, bound, previous, s->block_counts, s->count_stride, info, s->list);
         timer.end();
-        for (int cls : s->classes) {
-            timer.begin(8 + cls);
-            launch_bounce(g_stream, cls, bound, s->dev, b, current, next, s->results, s->list, info,
-                          s->d_statistics + static_cast<size_t>(cls) * N_STATISTICS * STATISTICS_SLOTS);
-            timer.end();
-            st.class_launches[cls]++;
-        }
+        timer.begin(0);
+        launch_bounce(g_stream, s->dev.class_mask ? bound : 0u, s->dev, b, current, next, s->results, s->list, info, s->block_counts,
+                      s->count_stride, s->d_statistics);
+        timer.end();
         const int slot = launched % INFO_RING;
         HIP_TRY(hipMemcpyAsync(&s->h_info[slot], info, sizeof(BinInfo), hipMemcpyDeviceToHost, g_stream));
         HIP_TRY(hipEventRecord(s->info_events[slot], g_stream));
         launched++;
         st.bounce_launch_rounds++;
-        st.bin_launches += 3;
-        st.bounce_launches += s->classes.size();
+        st.bin_launches += 2;
+        st.bounce_launches += 1;
     }
     unsigned long long* totals = s->d_statistics + static_cast<size_t>(N_CLASSES) * N_STATISTICS * STATISTICS_SLOTS;
     for (int cls : s->classes)
