@@ -8,22 +8,28 @@ namespace ptk {
 
 // number of whole or partial BIN_CHUNK runs in n records
 uint32_t bin_blocks(uint32_t n);
+// Chunk size, in rounds of one block (1..BIN_ROUNDS), the bounce that walks a list of at most `bound`
+// records should use; the pool it writes is then sorted with the same value.  k_generate always uses
+// BIN_ROUNDS.
+uint32_t chunk_rounds(uint32_t bound);
+// entries per class block_counts needs for pools of up to `records` records under chunk_rounds()
+uint32_t chunk_capacity(uint32_t records);
 
 // In every launcher `bound` is an upper bound of the number of records, used only to size the grid;
 // the kernels read the true counts from device memory (*previous: the summary of the bounce that wrote
 // the pool they read; *info: the summary of the sorted list they produce or walk), so the host never
 // has to wait for a count before it queues the next bounce.
-// block_counts: [N_CLASSES][count_stride] per-chunk class counts; count_stride >= bin_blocks(capacity) + N_CLASSES
+// block_counts: [N_CLASSES][count_stride] per-chunk class counts; count_stride >= chunk_capacity(capacity)
 void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathPool& pool, const SampleResults& res,
                      BinInfo* first_info, uint32_t* block_counts, uint32_t count_stride);
 // scan + scatter: class-sorted index list of the records of `pool` from the counts its writer left, summary in *info
-void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_t bound, const BinInfo* previous, uint32_t* block_counts,
-                uint32_t count_stride, BinInfo* info, uint32_t* list_out);
+void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_t bound, uint32_t rounds, const BinInfo* previous,
+                uint32_t* block_counts, uint32_t count_stride, BinInfo* info, uint32_t* list_out);
 // one vertex of every path; leaves the class counts of `out` in block_counts;
 // statistics: [N_CLASSES][STATISTICS_SLOTS][N_STATISTICS] per-class, per-block slots
-void launch_bounce(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
-                   const SampleResults& res, const uint32_t* list, const BinInfo* info, uint32_t* block_counts, uint32_t count_stride,
-                   unsigned long long* statistics);
+void launch_bounce(hipStream_t s, uint32_t bound, uint32_t rounds, const DevScene& sc, const BatchParams& b, const PathPool& in,
+                   const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info, uint32_t* block_counts,
+                   uint32_t count_stride, unsigned long long* statistics);
 void launch_sum_statistics(hipStream_t s, const unsigned long long* slots, unsigned long long* totals);
 void launch_accumulate(hipStream_t s, const BatchParams& b, const SampleResults& res, double* image, double* position, double* normal,
                        unsigned long long* pixel_counters);

@@ -184,33 +184,36 @@ PTK_DEV Vertex next_vertex(const DevScene& sc, const BatchParams& b, const V3& o
 
 // -------------------------------------------------------------------------------------------------
 // Chunks.  The records of a pool lie class by class (the order the last bounce wrote them in); a
-// chunk is up to BIN_CHUNK consecutive records of one class.  Chunks are numbered class by class,
+// chunk is up to rounds * BLOCK consecutive records of one class, where `rounds` (1..BIN_ROUNDS) is
+// chosen by the host for every pool: large chunks amortise the per-chunk work, small ones keep
+// every CU busy when few paths are left.  Chunks are numbered class by class,
 // which is also the order of the records, and are the unit of work of k_bounce (one block works
 // through one chunk at a time) and of the class sort (block_counts has one entry per class and
 // chunk).
 struct ChunkTable {
     uint32_t first_chunk[N_CLASSES + 1]; // chunks of class c: [first_chunk[c], first_chunk[c + 1])
 };
-PTK_DEV ChunkTable chunk_table(const BinInfo* info) {
+PTK_DEV ChunkTable chunk_table(const BinInfo* info, uint32_t chunk_size) {
     ChunkTable t;
     uint32_t running = 0;
 #pragma unroll
     for (int c = 0; c < N_CLASSES; c++) {
         t.first_chunk[c] = running;
-        running += (info->count[c] + BIN_CHUNK - 1) / BIN_CHUNK;
+        running += (info->count[c] + chunk_size - 1) / chunk_size;
     }
     t.first_chunk[N_CLASSES] = running;
     return t;
 }
 // class, first record and number of records of a chunk
-PTK_DEV void locate_chunk(const BinInfo* info, const ChunkTable& t, uint32_t chunk, int& cls, uint32_t& first, uint32_t& count) {
+PTK_DEV void locate_chunk(const BinInfo* info, const ChunkTable& t, uint32_t chunk_size, uint32_t chunk, int& cls, uint32_t& first,
+                          uint32_t& count) {
     cls = 0;
 #pragma unroll
     for (int c = 1; c < N_CLASSES; c++)
         if (chunk >= t.first_chunk[c]) cls = c;
-    const uint32_t offset = (chunk - t.first_chunk[cls]) * BIN_CHUNK;
+    const uint32_t offset = (chunk - t.first_chunk[cls]) * chunk_size;
     first = info->start[cls] + offset;
-    count = min(static_cast<uint32_t>(BIN_CHUNK), info->count[cls] - offset);
+    count = min(chunk_size, info->count[cls] - offset);
 }
 
 // Per-class counts of the records a block wrote for one chunk -> block_counts[class][chunk].
@@ -294,9 +297,9 @@ __global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, 
 // chunks of the pool `previous` describes, for every class in class_mask; one workgroup.  Leaves the offsets in place and the
 // per-class segment starts, counts and the total in `info`.  Tiles of 4096 counts: one uint4 per
 // thread, shuffles inside a wave, 16 wave sums through LDS, a running carry across tiles.
-__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* block_counts, uint32_t count_stride, uint32_t class_mask,
+__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* block_counts, uint32_t count_stride, uint32_t class_mask, uint32_t rounds,
                                                    const BinInfo* previous, BinInfo* info) {
-    const uint32_t n_blocks = chunk_table(previous).first_chunk[N_CLASSES];
+    const uint32_t n_blocks = chunk_table(previous, rounds * BLOCK).first_chunk[N_CLASSES];
     __shared__ uint32_t wave_sums[2][16];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t carry = 0; // the same in every thread
@@ -358,12 +361,12 @@ __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* block_counts, uint3
 // block_offsets[c][chunk] + (number of class-c records before it in its chunk).  Records of paths
 // that ended are left out.  One block per chunk of the pool `previous` describes.
 __global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathPool pool, const BinInfo* previous, const uint32_t* block_offsets,
-                                                       uint32_t count_stride, uint32_t class_mask, uint32_t* list_out) {
-    const ChunkTable table = chunk_table(previous);
+                                                       uint32_t count_stride, uint32_t class_mask, uint32_t rounds, uint32_t* list_out) {
+    const ChunkTable table = chunk_table(previous, rounds * BLOCK);
     if (blockIdx.x >= table.first_chunk[N_CLASSES]) return;
     int chunk_class;
     uint32_t first, n;
-    locate_chunk(previous, table, blockIdx.x, chunk_class, first, n);
+    locate_chunk(previous, table, rounds * BLOCK, blockIdx.x, chunk_class, first, n);
     __shared__ uint32_t counts[BIN_ROUNDS][BLOCK / 64][N_CLASSES];
     const int wave = threadIdx.x >> 6;
     int classes[BIN_ROUNDS];
@@ -570,14 +573,14 @@ PTK_DEV void shade_vertex(const DevScene& sc, const SampleResults& res, const De
 template<bool TRIS, bool UV>
 __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_bounce(DevScene sc, BatchParams b, PathPool in, PathPool out,
                                                                                       SampleResults res, const uint32_t* list,
-                                                                                      const BinInfo* info, uint32_t* block_counts,
-                                                                                      uint32_t count_stride,
+                                                                                      const BinInfo* info, uint32_t rounds,
+                                                                                      uint32_t* block_counts, uint32_t count_stride,
                                                                                       unsigned long long* statistics) {
     __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1];
     __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
     __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
     TraversalStack st = make_stack(lds_stack);
-    const ChunkTable table = chunk_table(info);
+    const ChunkTable table = chunk_table(info, rounds * BLOCK);
 #ifdef PTK_STAMPS
 #define PTK_STAMP(k)                                                                                   \
     {                                                                                                  \
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
     for (uint32_t chunk = blockIdx.x; chunk < table.first_chunk[N_CLASSES]; chunk += gridDim.x) {
         int cls;
         uint32_t first, n;
-        locate_chunk(info, table, chunk, cls, first, n);
+        locate_chunk(info, table, rounds * BLOCK, chunk, cls, first, n);
         uint32_t stat[N_STATISTICS] = {};
         uint32_t my_counts[N_CLASSES];
 #pragma unroll
@@ -604,7 +607,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
         Record cur{};
         if (qi < n) cur = load_record(in, list[first + qi]);
         uint32_t src_next = qi + BLOCK < n ? list[first + qi + BLOCK] : 0u;
-        for (int r = 0; r < BIN_ROUNDS && r * BLOCK < n; r++, qi += BLOCK) {
+        for (uint32_t r = 0; r * BLOCK < n; r++, qi += BLOCK) {
             const bool have = qi < n, have_next = qi + BLOCK < n;
             const uint32_t dst = first + qi;
             int new_cls = -1;
@@ -850,9 +853,24 @@ uint32_t bin_blocks(uint32_t n) {
     return n == 0 ? 1u : (n + BIN_CHUNK - 1) / BIN_CHUNK;
 }
 
-// blocks for a pool of at most `bound` records: its chunks (each class may end in a partial one)
-static inline uint32_t chunk_blocks(uint32_t bound) {
-    return bin_blocks(bound) + N_CLASSES;
+// chunks of a pool of at most `bound` records (each class may end in a partial one)
+static inline uint32_t chunk_blocks(uint32_t bound, uint32_t rounds) {
+    return (bound + rounds * BLOCK - 1) / (rounds * BLOCK) + N_CLASSES;
+}
+
+uint32_t chunk_rounds(uint32_t bound) {
+    const uint32_t r = bound / (BLOCK * 2048u); // aim at 2048 chunks or more: eight per CU
+    return r < 1 ? 1 : (r > BIN_ROUNDS ? BIN_ROUNDS : r);
+}
+
+uint32_t chunk_capacity(uint32_t records) {
+    uint32_t most = 0;
+    for (uint32_t r = 1; r <= BIN_ROUNDS; r++) {
+        // the largest pool the host chunks with r rounds
+        const uint64_t limit = r == BIN_ROUNDS ? records : std::min<uint64_t>(records, static_cast<uint64_t>(r + 1) * BLOCK * 2048u);
+        most = std::max(most, chunk_blocks(static_cast<uint32_t>(limit), r));
+    }
+    return most;
 }
 
 void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathPool& pool, const SampleResults& res,
@@ -862,19 +880,19 @@ void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, co
     else hipLaunchKernelGGL(k_generate<false>, grid, block, 0, s, sc, b, pool, res, first_info, block_counts, count_stride);
 }
 
-void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_t bound, const BinInfo* previous, uint32_t* block_counts,
-                uint32_t count_stride, BinInfo* info, uint32_t* list_out) {
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, block_counts, count_stride, sc.class_mask, previous, info);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(chunk_blocks(bound)), dim3(BLOCK), 0, s, pool, previous, block_counts, count_stride,
-                       sc.class_mask, list_out);
+void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_t bound, uint32_t rounds, const BinInfo* previous,
+                uint32_t* block_counts, uint32_t count_stride, BinInfo* info, uint32_t* list_out) {
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, block_counts, count_stride, sc.class_mask, rounds, previous, info);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(chunk_blocks(bound, rounds)), dim3(BLOCK), 0, s, pool, previous, block_counts, count_stride,
+                       sc.class_mask, rounds, list_out);
 }
 
-void launch_bounce(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
-                   const SampleResults& res, const uint32_t* list, const BinInfo* info, uint32_t* block_counts, uint32_t count_stride,
-                   unsigned long long* statistics) {
-    const dim3 grid(min(chunk_blocks(bound), static_cast<uint32_t>(STATISTICS_SLOTS))), block(BLOCK);
+void launch_bounce(hipStream_t s, uint32_t bound, uint32_t rounds, const DevScene& sc, const BatchParams& b, const PathPool& in,
+                   const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info, uint32_t* block_counts,
+                   uint32_t count_stride, unsigned long long* statistics) {
+    const dim3 grid(min(chunk_blocks(bound, rounds), static_cast<uint32_t>(STATISTICS_SLOTS))), block(BLOCK);
 #define PTK_LAUNCH_BOUNCE(T, U) \
-    hipLaunchKernelGGL((k_bounce<T, U>), grid, block, 0, s, sc, b, in, out, res, list, info, block_counts, count_stride, statistics)
+    hipLaunchKernelGGL((k_bounce<T, U>), grid, block, 0, s, sc, b, in, out, res, list, info, rounds, block_counts, count_stride, statistics)
     if (sc.has_triangles) {
         if (sc.needs_uv) PTK_LAUNCH_BOUNCE(true, true);
         else PTK_LAUNCH_BOUNCE(true, false);

@@ -197,7 +197,7 @@ int ensure_capacity(PtkScene* s, int64_t paths) {
     s->results.plane_doubles = n * 2;
     HIP_TRY(b.alloc(&s->results.surface, n * 6));
     HIP_TRY(b.alloc(&s->list, n));
-    s->count_stride = (bin_blocks(static_cast<uint32_t>(n)) + N_CLASSES + 3u) & ~3u; // one entry per chunk; rows stay 16-byte aligned
+    s->count_stride = (chunk_capacity(static_cast<uint32_t>(n)) + 3u) & ~3u; // one entry per chunk; rows stay 16-byte aligned
     HIP_TRY(b.alloc(&s->block_counts, static_cast<size_t>(s->count_stride) * N_CLASSES));
     s->capacity = paths;
     return PTK_OK;
@@ -276,6 +276,7 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
     st.algorithmic_bytes += GENERATE_BYTES_PER_PATH * b.n_paths;
 
     uint32_t bound = b.n_paths;     // newest known upper bound of the record count
+    uint32_t pool_rounds = BIN_ROUNDS; // chunk size (in rounds) the current pool was written with
     uint64_t records = b.n_paths;   // records the oldest unretired bounce walked
     uint64_t sum_records = 0, sum_vertices = 0;
     uint64_t class_vertices[N_CLASSES] = {};
@@ -310,10 +311,11 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
         BinInfo* previous = &s->d_info[(depth + 1) & 1];
         BinInfo* info = &s->d_info[depth & 1];
         timer.begin(1);
-        launch_bin(g_stream, s->dev, current, bound, previous, s->block_counts, s->count_stride, info, s->list);
+        launch_bin(g_stream, s->dev, current, bound, pool_rounds, previous, s->block_counts, s->count_stride, info, s->list);
         timer.end();
         timer.begin(0);
-        launch_bounce(g_stream, s->dev.class_mask ? bound : 0u, s->dev, b, current, next, s->results, s->list, info, s->block_counts,
+        pool_rounds = chunk_rounds(bound);
+        launch_bounce(g_stream, bound, pool_rounds, s->dev, b, current, next, s->results, s->list, info, s->block_counts,
                       s->count_stride, s->d_statistics);
         timer.end();
         const int slot = launched % INFO_RING;
