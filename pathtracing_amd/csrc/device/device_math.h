@@ -95,6 +95,17 @@ PTK_DEV bool solve_quadratic(double b, double c, double& distance) { // :52-71
     return false;
 }
 
+// solve_quadratic without branches, so that the tests of two rays interleave: the square root of a
+// negative discriminant is a NaN, which fails every comparison that follows.
+PTK_DEV bool solve_quadratic_select(double b, double c, double& distance) {
+    double discriminant = b * b - 4.0 * c;
+    double root = sqrt(discriminant);
+    double minimum_solution = -0.5 * (b + root), maximum_solution = -0.5 * (b - root);
+    bool minimum_ok = minimum_solution > EPSILON, maximum_ok = maximum_solution > EPSILON;
+    distance = minimum_ok ? minimum_solution : maximum_solution;
+    return discriminant > 0 && (minimum_ok || maximum_ok);
+}
+
 PTK_DEV V3 sample_spherical(Rng& rng) { // :73-80
     double r1 = rng.normal();
     double r2 = rng.normal();

@@ -173,22 +173,100 @@ PTK_DEV void load_shape(const PTK_CONSTANT DevShape* p, DevShape& s) {
     s.bvh_root = p->bvh_root;
 }
 
-// find_closest_hit (src/objects.cpp:414-442) without the attribute computation: the linear scan
-// over top-level objects with the shrinking t_max; first object wins exact ties.  The record of
-// object i + 1 is requested before object i is tested, so the scalar-load latency overlaps the
-// arithmetic.
-// TRIS = false compiles the triangle test and the BVH traversal (and with it the stack) out, for
-// scenes made of spheres, planes and rectangles only.
-template<bool TRIS>
-PTK_DEV bool closest_hit(const DevScene& sc, const V3& org, const V3& dir, double t_max, HitInfo& hit, TraversalStack& st) {
+// One object against one ray: the body of find_closest_hit's loop (src/objects.cpp:414-442) with the
+// primitive tests inlined; updates the closest hit so far and the shrinking t_max (`limit`).  First
+// object wins exact ties.  The analytic tests are written with selects instead of branches (same
+// arithmetic, same results): with two rays per object the compiler can then interleave their
+// dependent chains of fp64 operations.
+struct RayState {
+    V3 dir;
+    double dir_dot_org;
+    RayPrep rp;
+    double limit;
+    HitInfo hit;
+};
+
+PTK_DEV void accept_hit(RayState& r, bool success, double d, int index, int prim, int cls) {
+    if (success && d > EPSILON && d < r.hit.t) {
+        r.hit.t = d;
+        r.hit.obj = index;
+        r.hit.prim = prim;
+        r.hit.cls = cls;
+        r.limit = d;
+    }
+}
+
+template<bool TRIS, int N>
+PTK_DEV void test_shape(const DevScene& sc, const DevShape& o, int index, const V3& org, RayState (&rays)[N], TraversalStack& st) {
+    if (o.type == PTK_OBJ_SPHERE) { // :106-119
+        V3 c = v3(o.f[0], o.f[1], o.f[2]);
+        double cc = len2(c - org) - o.f[3] * o.f[3];
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            double d;
+            double b = 2 * (rays[k].dir_dot_org - dot(rays[k].dir, c));
+            bool success = solve_quadratic_select(b, cc, d) && !(d > rays[k].limit);
+            accept_hit(rays[k], success, d, index, 0, o.cls);
+        }
+    }
+    else if (o.type == PTK_OBJ_PLANE || o.type == PTK_OBJ_RECTANGLE) { // :185-211, :237-255
+        V3 nrm = v3(o.f[3], o.f[4], o.f[5]);
+        V3 shifted = org - v3(o.f[0], o.f[1], o.f[2]);
+        double shifted_dot_n = dot(shifted, nrm);
+        double d[N];
+        bool success[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            double ddn = -dot(rays[k].dir, nrm);
+            d[k] = shifted_dot_n / ddn;
+            success[k] = !(fabs(ddn) < EPSILON) && !(d[k] < EPSILON) && !(d[k] > rays[k].limit);
+        }
+        if (o.type == PTK_OBJ_RECTANGLE) {
+            V3 a1 = v3(o.f[6], o.f[7], o.f[8]), a2 = v3(o.f[9], o.f[10], o.f[11]);
+            double s1 = dot(shifted, a1), s2 = dot(shifted, a2);
+            double half1 = o.f[12] / 2.0 + EPSILON, half2 = o.f[13] / 2.0 + EPSILON;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                bool outside = fabs(s1 + dot(rays[k].dir, a1) * d[k]) > half1 || fabs(s2 + dot(rays[k].dir, a2) * d[k]) > half2;
+                success[k] = success[k] && !outside;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < N; k++) accept_hit(rays[k], success[k], d[k], index, 0, o.cls);
+    }
+    else if (TRIS && o.type == PTK_OBJ_TRIANGLE) {
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            double d = INF;
+            bool success = triangle_hit(sc.tri_hot[o.first_tri], org, rays[k].rp, rays[k].limit, d);
+            accept_hit(rays[k], success, d, index, o.first_tri, o.cls);
+        }
+    }
+    else if (TRIS) { // mesh
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            double tb = rays[k].limit;
+            int pb = -1;
+            mesh_closest_hit(sc, o.bvh_root, o.first_tri, org, rays[k].dir, rays[k].rp, tb, pb, st);
+            accept_hit(rays[k], pb >= 0, tb, index, pb, o.cls);
+        }
+    }
+}
+
+PTK_DEV void no_hit(HitInfo& hit) {
     hit.t = INF;
     hit.obj = -1;
     hit.prim = 0;
     hit.cls = 0;
-    RayPrep rp{};
-    if (TRIS) rp = prepare_ray(dir);
-    const double dir_dot_org = dot(dir, org);
-    double limit = t_max; // ray.t_max
+}
+
+// find_closest_hit (src/objects.cpp:414-442) without the attribute computation: the linear scan
+// over top-level objects.  The record of object i + 1 is requested before object i is tested, so the
+// scalar-load latency overlaps the arithmetic.
+// TRIS = false compiles the triangle test and the BVH traversal (and with it the stack) out, for
+// scenes made of spheres, planes and rectangles only.
+template<bool TRIS, int N>
+PTK_DEV void scan_objects(const DevScene& sc, const V3& org, RayState (&rays)[N], TraversalStack& st) {
     const PTK_CONSTANT DevShape* shapes = (const PTK_CONSTANT DevShape*) sc.shapes;
     const int n = sc.n_objects;
     DevShape o;
@@ -200,54 +278,42 @@ PTK_DEV bool closest_hit(const DevScene& sc, const V3& org, const V3& dir, doubl
     for (int i = 0; i < n; i++) {
         DevShape next;
         load_shape(shapes + (i + 1 < n ? i + 1 : i), next);
-        double d = INF;
-        int prim = 0;
-        bool success = false;
-        if (o.type == PTK_OBJ_SPHERE) { // :106-119
-            V3 c = v3(o.f[0], o.f[1], o.f[2]);
-            double b = 2 * (dir_dot_org - dot(dir, c));
-            double cc = len2(c - org) - o.f[3] * o.f[3];
-            success = solve_quadratic(b, cc, d) && !(d > limit);
-        }
-        else if (o.type == PTK_OBJ_PLANE || o.type == PTK_OBJ_RECTANGLE) { // :185-211, :237-255
-            V3 nrm = v3(o.f[3], o.f[4], o.f[5]);
-            V3 shifted = org - v3(o.f[0], o.f[1], o.f[2]);
-            double ddn = -dot(dir, nrm);
-            if (!(fabs(ddn) < EPSILON)) {
-                d = dot(shifted, nrm) / ddn;
-                success = !(d < EPSILON) && !(d > limit);
-                if (success && o.type == PTK_OBJ_RECTANGLE) {
-                    V3 a1 = v3(o.f[6], o.f[7], o.f[8]), a2 = v3(o.f[9], o.f[10], o.f[11]);
-                    if (fabs(dot(shifted, a1) + dot(dir, a1) * d) > o.f[12] / 2.0 + EPSILON ||
-                        fabs(dot(shifted, a2) + dot(dir, a2) * d) > o.f[13] / 2.0 + EPSILON)
-                        success = false;
-                }
-            }
-        }
-        else if (TRIS && o.type == PTK_OBJ_TRIANGLE) {
-            success = triangle_hit(sc.tri_hot[o.first_tri], org, rp, limit, d);
-            prim = o.first_tri;
-        }
-        else if (TRIS) { // mesh
-            double tb = limit;
-            int pb = -1;
-            mesh_closest_hit(sc, o.bvh_root, o.first_tri, org, dir, rp, tb, pb, st);
-            if (pb >= 0) {
-                success = true;
-                d = tb;
-                prim = pb;
-            }
-        }
-        if (success && d > EPSILON && d < hit.t) {
-            hit.t = d;
-            hit.obj = i;
-            hit.prim = prim;
-            hit.cls = o.cls;
-            limit = d;
-        }
+        test_shape<TRIS, N>(sc, o, i, org, rays, st);
         o = next;
     }
+}
+
+template<bool TRIS>
+PTK_DEV RayState ray_state(const V3& org, const V3& dir, double t_max) {
+    RayState r;
+    r.dir = dir;
+    r.dir_dot_org = dot(dir, org);
+    r.rp = RayPrep{};
+    if (TRIS) r.rp = prepare_ray(dir);
+    r.limit = t_max; // ray.t_max
+    no_hit(r.hit);
+    return r;
+}
+
+template<bool TRIS>
+PTK_DEV bool closest_hit(const DevScene& sc, const V3& org, const V3& dir, double t_max, HitInfo& hit, TraversalStack& st) {
+    RayState rays[1] = {ray_state<TRIS>(org, dir, t_max)};
+    scan_objects<TRIS, 1>(sc, org, rays, st);
+    hit = rays[0].hit;
     return hit.obj >= 0;
+}
+
+// Two rays from one origin through one pass over the objects (a shadow ray and an extension ray
+// leave every shaded vertex together): half the object records to fetch, shared per-object terms,
+// and two independent chains of arithmetic per object.  A ray that is not wanted is given
+// t_max = -infinity, which no primitive test accepts.
+template<bool TRIS>
+PTK_DEV void closest_hit_pair(const DevScene& sc, const V3& org, const V3& dir_a, double t_max_a, HitInfo& hit_a, const V3& dir_b,
+                              double t_max_b, HitInfo& hit_b, TraversalStack& st) {
+    RayState rays[2] = {ray_state<TRIS>(org, dir_a, t_max_a), ray_state<TRIS>(org, dir_b, t_max_b)};
+    scan_objects<TRIS, 2>(sc, org, rays, st);
+    hit_a = rays[0].hit;
+    hit_b = rays[1].hit;
 }
 
 // ---- surface attributes --------------------------------------------------------------------

@@ -150,13 +150,13 @@ struct Vertex {
     int obj, prim, cls;
 };
 
-template<bool TRIS>
-PTK_DEV Vertex next_vertex(const DevScene& sc, const BatchParams& b, const V3& org, const V3& dir, uint32_t medium, uint32_t sid,
-                           uint32_t ctr, TraversalStack& st) {
+// HomogenousScatteringMedium::sample_distance (src/medium.cpp:45-51) for the medium the new ray
+// starts in; infinity elsewhere.
+PTK_DEV double free_flight_distance(const DevScene& sc, const BatchParams& b, uint32_t medium, uint32_t sid, uint32_t ctr) {
     if (medium == MEDIUM_NONE) medium = static_cast<uint32_t>(sc.background_medium);
     const DevMedium& med = sc.media[medium];
     double scatter_distance = INF;
-    if (med.type == PTK_MEDIUM_HOMOGENEOUS_SCATTERING) { // HomogenousScatteringMedium::sample_distance
+    if (med.type == PTK_MEDIUM_HOMOGENEOUS_SCATTERING) {
         uint32_t pixel, sample;
         sample_coordinates(b, sid, pixel, sample);
         Rng rng{rng_key(b.seed, pixel, sample), ctr};
@@ -164,10 +164,12 @@ PTK_DEV Vertex next_vertex(const DevScene& sc, const BatchParams& b, const V3& o
         double ext = med.extinction[channel];
         if (ext != 0) scatter_distance = -log(rng.u01()) / ext;
     }
-    HitInfo h;
-    const bool found = closest_hit<TRIS>(sc, org, dir, scatter_distance, h, st);
+    return scatter_distance;
+}
+
+PTK_DEV Vertex vertex_of(const HitInfo& h, double scatter_distance) {
     Vertex v;
-    if (found) {
+    if (h.obj >= 0) {
         v.t = h.t;
         v.obj = h.obj;
         v.prim = h.prim;
@@ -180,6 +182,15 @@ PTK_DEV Vertex next_vertex(const DevScene& sc, const BatchParams& b, const V3& o
         v.cls = scatter_distance == INF ? -1 : CLASS_SCATTER;
     }
     return v;
+}
+
+template<bool TRIS>
+PTK_DEV Vertex next_vertex(const DevScene& sc, const BatchParams& b, const V3& org, const V3& dir, uint32_t medium, uint32_t sid,
+                           uint32_t ctr, TraversalStack& st) {
+    const double scatter_distance = free_flight_distance(sc, b, medium, sid, ctr);
+    HitInfo h;
+    closest_hit<TRIS>(sc, org, dir, scatter_distance, h, st);
+    return vertex_of(h, scatter_distance);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -674,24 +685,30 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
                 if (have_next) nxt = load_record(in, src_next);
                 if (qi + 2 * BLOCK < n) src_after = list[first + qi + 2 * BLOCK];
 
-                // the connection: compute_visibility (src/objects.cpp:470-513) and the acceptance test
-                // of sample_light (:558), on its own forked random-number stream
+                // The shadow ray of the connection and the extension ray (the head of the next loop
+                // iteration: where does the new ray end) leave the vertex together.
+                const uint32_t medium_bits = v.next_medium < 0 ? MEDIUM_NONE : static_cast<uint32_t>(v.next_medium);
+                double scatter_distance = INF;
+                if (alive) scatter_distance = free_flight_distance(sc, b, medium_bits, v.sid, v.rng.ctr);
+                HitInfo shadow_hit, extension_hit;
+                closest_hit_pair<TRIS>(sc, v.point, v.sh_dir, v.connect ? INF : -INF, shadow_hit, v.n_dir, alive ? scatter_distance : -INF,
+                                       extension_hit, st);
+                // compute_visibility (src/objects.cpp:470-513) and the acceptance test of sample_light
+                // (:558), on its own forked random-number stream
                 if (v.connect) {
                     Rng march_rng{v.sh_key, 0};
                     stat[2]++;
+                    stat[0]++;
                     V3 visible = march_to_light<TRIS, UV>(sc, v.point, v.sh_dir, static_cast<int>(v.medium), v.light_index, v.sh_dist,
-                                                          march_rng, st, stat[0]);
+                                                          march_rng, st, stat[0], shadow_hit);
                     v.color = v.color + v.sh_contrib * visible;
                 }
                 PTK_STAMP(1)
-
-                // the head of the next loop iteration: where does the new ray end
                 Vertex nv;
                 nv.cls = -1;
-                const uint32_t medium_bits = v.next_medium < 0 ? MEDIUM_NONE : static_cast<uint32_t>(v.next_medium);
                 if (alive) {
                     stat[1]++;
-                    nv = next_vertex<TRIS>(sc, b, v.point, v.n_dir, medium_bits, v.sid, v.rng.ctr, st);
+                    nv = vertex_of(extension_hit, scatter_distance);
                     if (nv.cls < 0 && !sc.background_is_black) v.color = v.color + v.thr * v3(sc.background);
                 }
                 PTK_STAMP(2)

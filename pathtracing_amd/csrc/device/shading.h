@@ -345,15 +345,15 @@ PTK_DEV bool pick_light_point(const DevScene& sc, int shaded_object, const V3& f
 // compute_visibility (src/objects.cpp:470-513) plus sample_light's acceptance test (:558):
 // marches towards the light through surfaces that let direct light pass, multiplying the
 // transmittance of each segment's medium.  Returns emittance * transmittance, or black.
+// `h` holds the closest hit of the first segment (found by the caller, together with the
+// extension ray); later segments are traced here.
 template<bool TRIS, bool UV>
 PTK_DEV V3 march_to_light(const DevScene& sc, V3 org, const V3& dir, int medium, int light_index, double distance_to_light,
-                          Rng& rng, TraversalStack& st, uint32_t& rays) {
+                          Rng& rng, TraversalStack& st, uint32_t& rays, HitInfo h) {
     V3 transmittance = v3(1.0);
     double distance = 0;
     for (;;) {
-        HitInfo h;
-        rays++;
-        if (!closest_hit<TRIS>(sc, org, dir, INF, h, st)) return v3(0.0);
+        if (h.obj < 0) return v3(0.0);
         distance += h.t;
         if (medium < 0) medium = sc.background_medium;
         transmittance = transmittance * medium_transmittance(sc.media[medium], h.t);
@@ -374,6 +374,8 @@ PTK_DEV V3 march_to_light(const DevScene& sc, V3 org, const V3& dir, int medium,
         bool outside = dot(dir, normal) < 0;
         org = point;
         medium = outside ? m.internal_medium : m.external_medium;
+        rays++;
+        closest_hit<TRIS>(sc, org, dir, INF, h, st);
     }
 }
 
