@@ -203,7 +203,8 @@ def main():
     uv = "true" if any(big(m) for k in range(hs.n_materials)
                        for m in (hs.materials[k].albedo_map, hs.materials[k].emission_color_map, hs.materials[k].light_intensity_map,
                                  hs.materials[k].roughness_map, hs.materials[k].transparency_map)) else "false"
-    kernel = f"ptk::k_bounce<{tris}, {uv}>"
+    defer = "true" if any(hs.objects[i].type == pt._ffi.PTK_OBJ_MESH for i in range(hs.n_objects)) else "false"
+    kernel = f"ptk::k_bounce<{tris}, {uv}, {defer}>"
     achieved = d_bytes / (d_ms * 1e-3) / 1e9 if d_ms > 0 else 0.0
     traffic = None
     traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")

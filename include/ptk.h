@@ -192,9 +192,8 @@ typedef struct PtkStats {
     double bounce_ms, bin_ms, other_ms, reserved_ms; /* device time per family, HIP events, while profiling is on */
     uint64_t bounce_launches, bin_launches, reserved_launches;
     uint64_t bounce_bytes, bin_bytes, reserved_bytes; /* algorithmic bytes per family */
-    /* The bounce family per class (PTK_MAT_* order, then medium scattering): vertices shaded and
-     * algorithmic bytes. */
-    uint64_t class_vertices[8], class_bytes[8];
+    /* Vertices shaded per class (PTK_MAT_* order, then medium scattering). */
+    uint64_t class_vertices[8];
 } PtkStats;
 
 /* Selects the GPU for this process (hipSetDevice) and creates the library's stream.

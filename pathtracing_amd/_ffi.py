@@ -68,7 +68,7 @@ class PtkStats(C.Structure):
                 ("bounce_ms", C.c_double), ("bin_ms", C.c_double), ("other_ms", C.c_double),
                 ("reserved_ms", C.c_double), ("bounce_launches", C.c_uint64), ("bin_launches", C.c_uint64),
                 ("reserved_launches", C.c_uint64), ("bounce_bytes", C.c_uint64), ("bin_bytes", C.c_uint64),
-                ("reserved_bytes", C.c_uint64), ("class_vertices", C.c_uint64 * 8), ("class_bytes", C.c_uint64 * 8)]
+                ("reserved_bytes", C.c_uint64), ("class_vertices", C.c_uint64 * 8)]
 
 
 class PtkDenoiseTask(C.Structure):

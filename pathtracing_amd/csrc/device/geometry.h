@@ -80,6 +80,9 @@ struct TraversalStack {
     int stride;
     StackEntry spill[SPILL_STACK_DEPTH];
     int sp;
+#ifdef PTK_STAMPS
+    uint32_t nodes_visited = 0, triangles_tested = 0; // profiling build
+#endif
     PTK_DEV void push(int32_t node, float tnear) {
         StackEntry e{node, tnear};
         if (sp < LDS_STACK_DEPTH) lds[sp * stride] = e;
@@ -109,6 +112,9 @@ PTK_DEV void mesh_closest_hit(const DevScene& sc, int32_t bvh_root, int64_t firs
             uint32_t code = static_cast<uint32_t>(~e.node);
             int64_t first = first_tri + (code >> 3);
             int count = static_cast<int>(code & 7u) + 1;
+#ifdef PTK_STAMPS
+            st.triangles_tested += count;
+#endif
             for (int i = 0; i < count; i++) {
                 double d;
                 if (triangle_hit(sc.tri_hot[first + i], org, rp, t_best, d) && d > EPSILON && d < t_best) {
@@ -118,6 +124,9 @@ PTK_DEV void mesh_closest_hit(const DevScene& sc, int32_t bvh_root, int64_t firs
             }
             continue;
         }
+#ifdef PTK_STAMPS
+        st.nodes_visited++;
+#endif
         const BvhNode4& n = sc.nodes[e.node];
         float tn[4];
         int32_t ch[4];
@@ -184,7 +193,27 @@ struct RayState {
     RayPrep rp;
     double limit;
     HitInfo hit;
+    bool needs_mesh; // MESH_DEFER: the ray enters the bounds of some mesh before its limit
 };
+// What the object scan does with a mesh: walk its hierarchy, only test its bounds (and leave the
+// walk to k_traverse), or nothing (the walk has been done).
+enum MeshMode : int { MESH_INLINE = 0, MESH_DEFER = 1, MESH_SKIP = 2 };
+
+// Entry distance of the ray into an axis-aligned box, +infinity when it misses (BoundingBox::intersect,
+// src/bvh.cpp:60-83).
+PTK_DEV double box_entry(const double* bounds, const V3& org, const V3& dir) {
+    double t0 = (bounds[0] - org.x) / dir.x, t1 = (bounds[3] - org.x) / dir.x;
+    double lo = fmax(0.0, fmin(t0, t1)), hi = fmax(t0, t1);
+    t0 = (bounds[1] - org.y) / dir.y;
+    t1 = (bounds[4] - org.y) / dir.y;
+    lo = fmax(lo, fmin(t0, t1));
+    hi = fmin(hi, fmax(t0, t1));
+    t0 = (bounds[2] - org.z) / dir.z;
+    t1 = (bounds[5] - org.z) / dir.z;
+    lo = fmax(lo, fmin(t0, t1));
+    hi = fmin(hi, fmax(t0, t1));
+    return hi >= lo ? lo : INF;
+}
 
 PTK_DEV void accept_hit(RayState& r, bool success, double d, int index, int prim, int cls) {
     if (success && d > EPSILON && d < r.hit.t) {
@@ -196,7 +225,7 @@ PTK_DEV void accept_hit(RayState& r, bool success, double d, int index, int prim
     }
 }
 
-template<bool TRIS, int N>
+template<bool TRIS, int MODE, int N>
 PTK_DEV void test_shape(const DevScene& sc, const DevShape& o, int index, const V3& org, RayState (&rays)[N], TraversalStack& st) {
     if (o.type == PTK_OBJ_SPHERE) { // :106-119
         V3 c = v3(o.f[0], o.f[1], o.f[2]);
@@ -242,7 +271,12 @@ PTK_DEV void test_shape(const DevScene& sc, const DevShape& o, int index, const 
             accept_hit(rays[k], success, d, index, o.first_tri, o.cls);
         }
     }
-    else if (TRIS) { // mesh
+    else if (TRIS && MODE == MESH_DEFER) { // mesh: bounds only
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            if (o.bvh_root >= 0 && box_entry(o.f, org, rays[k].dir) < rays[k].limit) rays[k].needs_mesh = true;
+    }
+    else if (TRIS && MODE == MESH_INLINE) { // mesh
 #pragma unroll
         for (int k = 0; k < N; k++) {
             double tb = rays[k].limit;
@@ -261,11 +295,14 @@ PTK_DEV void no_hit(HitInfo& hit) {
 }
 
 // find_closest_hit (src/objects.cpp:414-442) without the attribute computation: the linear scan
-// over top-level objects.  The record of object i + 1 is requested before object i is tested, so the
-// scalar-load latency overlaps the arithmetic.
+// over top-level objects, for N rays that leave one origin together (a shadow ray and an extension
+// ray leave every shaded vertex): one fetch of every object record, shared per-object terms, and N
+// independent chains of arithmetic per object.  A ray that is not wanted is given
+// t_max = -infinity, which no primitive test accepts.  The record of object i + 1 is requested
+// before object i is tested, so the scalar-load latency overlaps the arithmetic.
 // TRIS = false compiles the triangle test and the BVH traversal (and with it the stack) out, for
 // scenes made of spheres, planes and rectangles only.
-template<bool TRIS, int N>
+template<bool TRIS, int MODE, int N>
 PTK_DEV void scan_objects(const DevScene& sc, const V3& org, RayState (&rays)[N], TraversalStack& st) {
     const PTK_CONSTANT DevShape* shapes = (const PTK_CONSTANT DevShape*) sc.shapes;
     const int n = sc.n_objects;
@@ -278,7 +315,7 @@ PTK_DEV void scan_objects(const DevScene& sc, const V3& org, RayState (&rays)[N]
     for (int i = 0; i < n; i++) {
         DevShape next;
         load_shape(shapes + (i + 1 < n ? i + 1 : i), next);
-        test_shape<TRIS, N>(sc, o, i, org, rays, st);
+        test_shape<TRIS, MODE, N>(sc, o, i, org, rays, st);
         o = next;
     }
 }
@@ -292,28 +329,16 @@ PTK_DEV RayState ray_state(const V3& org, const V3& dir, double t_max) {
     if (TRIS) r.rp = prepare_ray(dir);
     r.limit = t_max; // ray.t_max
     no_hit(r.hit);
+    r.needs_mesh = false;
     return r;
 }
 
 template<bool TRIS>
 PTK_DEV bool closest_hit(const DevScene& sc, const V3& org, const V3& dir, double t_max, HitInfo& hit, TraversalStack& st) {
     RayState rays[1] = {ray_state<TRIS>(org, dir, t_max)};
-    scan_objects<TRIS, 1>(sc, org, rays, st);
+    scan_objects<TRIS, MESH_INLINE, 1>(sc, org, rays, st);
     hit = rays[0].hit;
     return hit.obj >= 0;
-}
-
-// Two rays from one origin through one pass over the objects (a shadow ray and an extension ray
-// leave every shaded vertex together): half the object records to fetch, shared per-object terms,
-// and two independent chains of arithmetic per object.  A ray that is not wanted is given
-// t_max = -infinity, which no primitive test accepts.
-template<bool TRIS>
-PTK_DEV void closest_hit_pair(const DevScene& sc, const V3& org, const V3& dir_a, double t_max_a, HitInfo& hit_a, const V3& dir_b,
-                              double t_max_b, HitInfo& hit_b, TraversalStack& st) {
-    RayState rays[2] = {ray_state<TRIS>(org, dir_a, t_max_a), ray_state<TRIS>(org, dir_b, t_max_b)};
-    scan_objects<TRIS, 2>(sc, org, rays, st);
-    hit_a = rays[0].hit;
-    hit_b = rays[1].hit;
 }
 
 // ---- surface attributes --------------------------------------------------------------------

@@ -26,10 +26,10 @@ void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, co
 void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_t bound, uint32_t rounds, const BinInfo* previous,
                 uint32_t* block_counts, uint32_t count_stride, BinInfo* info, uint32_t* list_out);
 // one vertex of every path; leaves the class counts of `out` in block_counts;
-// statistics: [N_CLASSES][STATISTICS_SLOTS][N_STATISTICS] per-class, per-block slots
+// statistics: [STATISTICS_SLOTS][N_STATISTICS] per-block slots; queues: used by scenes with meshes
 void launch_bounce(hipStream_t s, uint32_t bound, uint32_t rounds, const DevScene& sc, const BatchParams& b, const PathPool& in,
                    const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info, uint32_t* block_counts,
-                   uint32_t count_stride, unsigned long long* statistics);
+                   uint32_t count_stride, unsigned long long* statistics, const DeferQueues& queues);
 void launch_sum_statistics(hipStream_t s, const unsigned long long* slots, unsigned long long* totals);
 void launch_accumulate(hipStream_t s, const BatchParams& b, const SampleResults& res, double* image, double* position, double* normal,
                        unsigned long long* pixel_counters);

@@ -36,6 +36,9 @@ constexpr int BLOCK = 256;
 #ifndef PTK_BOUNCE_WAVES
 #define PTK_BOUNCE_WAVES 2
 #endif
+#ifndef PTK_TRAVERSE_WAVES
+#define PTK_TRAVERSE_WAVES 4
+#endif
 #define PTK_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 static_assert(BLOCK == BIN_BLOCK, "k_extend and the bin kernels share their block geometry");
 
@@ -573,23 +576,142 @@ PTK_DEV void shade_vertex(const DevScene& sc, const SampleResults& res, const De
     }
 }
 
+// Record -> vertex, the shading of its class, Russian roulette (app/pathtracer.cpp:69-171 without the
+// ray casts).  Returns whether the path continues.
+template<bool TRIS, bool UV>
+PTK_DEV bool shade_record(const DevScene& sc, const BatchParams& b, const SampleResults& res, const Record& cur, int cls, PathVertex& v) {
+    const V3 org = v3(cur.r0.x, cur.r0.y, cur.r1.x);
+    v.dir = v3(cur.r1.y, cur.r2.x, cur.r2.y);
+    v.thr = v3(cur.t0.x, cur.t0.y, cur.t1.x);
+    v.saved = v3(cur.v0.x, cur.v0.y, cur.v1.x);
+    v.color = v3(cur.v1.y, cur.cc.x, cur.cc.y);
+    v.scatter_pdf = cur.t1.y;
+    const uint32_t flags = cur.hit.z;
+    v.sid = cur.hit.w;
+    v.depth = flags & DEPTH_MASK;
+    v.ray_type = (flags >> TYPE_SHIFT) & 3u;
+    v.has_hit = (flags & FLAG_HAS_HIT) != 0;
+    v.medium = flags >> 16;
+    if (v.medium == MEDIUM_NONE) v.medium = static_cast<uint32_t>(sc.background_medium);
+    const DevMedium& med = sc.media[v.medium];
+    uint32_t pixel, sample;
+    sample_coordinates(b, v.sid, pixel, sample);
+    v.rng = Rng{rng_key(b.seed, pixel, sample), cur.ids.x};
+    if (med.type == PTK_MEDIUM_HOMOGENEOUS_SCATTERING) {
+        // the numbers drawn for the free-flight distance when this vertex was found: the channel,
+        // and the distance only when that channel attenuates (src/medium.cpp:45-51)
+        int channel = v.rng.integer(0, 3);
+        if (med.extinction[channel] != 0) v.rng.ctr++;
+    }
+    v.t = __hiloint2double(static_cast<int>(cur.hit.y), static_cast<int>(cur.hit.x));
+    v.point = org + v.dir * v.t;
+    v.obj = static_cast<int>(cur.ids.y);
+    v.prim = static_cast<int>(cur.ids.z);
+    v.next_medium = static_cast<int>(v.medium);
+    v.connect = false;
+    v.light_index = 0;
+    v.sh_dir = v3(0.0);
+    v.sh_contrib = v3(0.0);
+    v.sh_dist = 0;
+    v.sh_key = 0;
+    switch (cls) {
+        case 0: shade_vertex<0, TRIS, UV>(sc, res, med, v); break;
+        case 1: shade_vertex<1, TRIS, UV>(sc, res, med, v); break;
+        case 2: shade_vertex<2, TRIS, UV>(sc, res, med, v); break;
+        case 3: shade_vertex<3, TRIS, UV>(sc, res, med, v); break;
+        case 4: shade_vertex<4, TRIS, UV>(sc, res, med, v); break;
+        case 5: shade_vertex<5, TRIS, UV>(sc, res, med, v); break;
+        case 6: shade_vertex<6, TRIS, UV>(sc, res, med, v); break;
+        default: shade_vertex<CLASS_SCATTER, TRIS, UV>(sc, res, med, v); break;
+    }
+    // Russian roulette :157-171
+    bool allow = true;
+    if (static_cast<int>(v.depth) >= sc.min_depth) {
+        double threshold = fmin(vmax(v.thr), 0.9);
+        allow = v.rng.u01() < threshold;
+        if (allow) v.thr = v.thr / threshold;
+    }
+    return allow && static_cast<int>(v.depth) + 1 <= sc.max_depth;
+}
+
+PTK_DEV uint32_t medium_bits_of(const PathVertex& v) {
+    return v.next_medium < 0 ? MEDIUM_NONE : static_cast<uint32_t>(v.next_medium);
+}
+
+// The two rays that leave a shaded vertex: [0] the shadow ray of the connection, [1] the extension
+// ray up to its free-flight distance.  A ray that is not wanted gets t_max = -infinity.
+template<bool TRIS>
+PTK_DEV void vertex_rays(const PathVertex& v, bool alive, double scatter_distance, RayState (&rays)[2]) {
+    rays[0] = ray_state<TRIS>(v.point, v.sh_dir, v.connect ? INF : -INF);
+    rays[1] = ray_state<TRIS>(v.point, v.n_dir, alive ? scatter_distance : -INF);
+}
+
+// The rest of the vertex once the closest hits of its two rays are known: the visibility march
+// (compute_visibility, src/objects.cpp:470-513, and the acceptance test of sample_light :558, on its
+// own forked random-number stream), the head of the next loop iteration (app/pathtracer.cpp:53-67:
+// where does the new ray end), and the record of the continuing path.  Returns the class of the
+// next vertex, -1 when the path ended.
+template<bool TRIS, bool UV>
+PTK_DEV int finish_vertex(const DevScene& sc, const PathPool& out, const SampleResults& res, uint32_t dst, PathVertex& v, bool alive,
+                          double scatter_distance, const HitInfo& shadow_hit, const HitInfo& extension_hit, TraversalStack& st,
+                          uint32_t* stat) {
+    if (v.connect) {
+        Rng march_rng{v.sh_key, 0};
+        stat[2]++;
+        stat[0]++;
+        V3 visible = march_to_light<TRIS, UV>(sc, v.point, v.sh_dir, static_cast<int>(v.medium), v.light_index, v.sh_dist, march_rng, st,
+                                              stat[0], shadow_hit);
+        v.color = v.color + v.sh_contrib * visible;
+    }
+    Vertex nv;
+    nv.cls = -1;
+    if (alive) {
+        stat[1]++;
+        nv = vertex_of(extension_hit, scatter_distance);
+        if (nv.cls < 0 && !sc.background_is_black) v.color = v.color + v.thr * v3(sc.background);
+    }
+    if (nv.cls < 0) { // the path ended here
+        flush_color(res, v.sid, v.color.x, v.color.y, v.color.z);
+        out.cls[dst] = CLASS_DONE;
+        return -1;
+    }
+    stat[3]++;
+    st2(out, PL_RAY0, dst, v.point.x, v.point.y);
+    st2(out, PL_RAY1, dst, v.point.z, v.n_dir.x);
+    st2(out, PL_RAY2, dst, v.n_dir.y, v.n_dir.z);
+    st2(out, PL_THR0, dst, v.thr.x, v.thr.y);
+    st2(out, PL_THR1, dst, v.thr.z, v.scatter_pdf);
+    st2(out, PL_SAV0, dst, v.saved.x, v.saved.y);
+    st2(out, PL_SAV1, dst, v.saved.z, v.color.x);
+    st2(out, PL_COL, dst, v.color.y, v.color.z);
+    stu4(out, PL_HIT, dst, static_cast<uint32_t>(__double2loint(nv.t)), static_cast<uint32_t>(__double2hiint(nv.t)),
+         (v.depth + 1) | (v.ray_type << TYPE_SHIFT) | (v.has_hit ? FLAG_HAS_HIT : 0u) | (medium_bits_of(v) << 16), v.sid);
+    stu4(out, PL_IDS, dst, v.rng.ctr, static_cast<uint32_t>(nv.obj), static_cast<uint32_t>(nv.prim), 0u);
+    out.cls[dst] = static_cast<uint8_t>(nv.cls);
+    return nv.cls;
+}
+
 // One vertex of every path: the loop body of raytrace (app/pathtracer.cpp:69-171) followed by the
 // head of its next iteration (:53-67).  A block works through chunks of the class-sorted list (every
-// chunk is of one class, so the class switch below is a scalar branch); for chunk records
+// chunk is of one class, so the class switch is a scalar branch); for chunk records
 // [first, first + n) it reads record list[first + j] of `in` and writes record first + j of `out`,
 // and leaves the counts of the classes it wrote in block_counts[class][chunk].
 // TRIS: the scene has triangles or meshes; UV: some material reads a map larger than 1x1 (texture
 // coordinates are needed).  Scenes without them get kernels without that code and its registers.
-// statistics: per class and block [class][STATISTICS_SLOTS][N_STATISTICS].
-template<bool TRIS, bool UV>
+// DEFER: vertices with a ray that enters the bounds of a mesh are queued for k_traverse and
+// k_bounce_resume instead of being finished here.
+// statistics: per block [STATISTICS_SLOTS][N_STATISTICS].
+template<bool TRIS, bool UV, bool DEFER>
 __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_bounce(DevScene sc, BatchParams b, PathPool in, PathPool out,
                                                                                       SampleResults res, const uint32_t* list,
                                                                                       const BinInfo* info, uint32_t rounds,
                                                                                       uint32_t* block_counts, uint32_t count_stride,
-                                                                                      unsigned long long* statistics) {
-    __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1];
+                                                                                      unsigned long long* statistics, DeferQueues queues) {
+    __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1]; // DEFER: later segments of a visibility march still walk inline
     __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
     __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
+    __shared__ uint32_t queue_counts[BLOCK / 64][2];
+    __shared__ uint32_t queue_base[2];
     TraversalStack st = make_stack(lds_stack);
     const ChunkTable table = chunk_table(info, rounds * BLOCK);
 #ifdef PTK_STAMPS
@@ -616,7 +738,8 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
         // casts), and its list entry one round earlier still, so neither latency is paid at the top.
         uint32_t qi = threadIdx.x;
         Record cur{};
-        if (qi < n) cur = load_record(in, list[first + qi]);
+        uint32_t src = qi < n ? list[first + qi] : 0u;
+        if (qi < n) cur = load_record(in, src);
         uint32_t src_next = qi + BLOCK < n ? list[first + qi + BLOCK] : 0u;
         for (uint32_t r = 0; r * BLOCK < n; r++, qi += BLOCK) {
             const bool have = qi < n, have_next = qi + BLOCK < n;
@@ -624,125 +747,159 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
             int new_cls = -1;
             Record nxt{};
             uint32_t src_after = 0;
+            RayState rays[2];
+            bool deferred = false;
+            V3 origin = v3(0.0);
             if (have) {
                 PathVertex v;
-                const V3 org = v3(cur.r0.x, cur.r0.y, cur.r1.x);
-                v.dir = v3(cur.r1.y, cur.r2.x, cur.r2.y);
-                v.thr = v3(cur.t0.x, cur.t0.y, cur.t1.x);
-                v.saved = v3(cur.v0.x, cur.v0.y, cur.v1.x);
-                v.color = v3(cur.v1.y, cur.cc.x, cur.cc.y);
-                v.scatter_pdf = cur.t1.y;
-                const uint32_t flags = cur.hit.z;
-                v.sid = cur.hit.w;
-                v.depth = flags & DEPTH_MASK;
-                v.ray_type = (flags >> TYPE_SHIFT) & 3u;
-                v.has_hit = (flags & FLAG_HAS_HIT) != 0;
-                v.medium = flags >> 16;
-                if (v.medium == MEDIUM_NONE) v.medium = static_cast<uint32_t>(sc.background_medium);
-                const DevMedium& med = sc.media[v.medium];
-                uint32_t pixel, sample;
-                sample_coordinates(b, v.sid, pixel, sample);
-                v.rng = Rng{rng_key(b.seed, pixel, sample), cur.ids.x};
-                if (med.type == PTK_MEDIUM_HOMOGENEOUS_SCATTERING) {
-                    // the numbers drawn for the free-flight distance when this vertex was found: the
-                    // channel, and the distance only when that channel attenuates (src/medium.cpp:45-51)
-                    int channel = v.rng.integer(0, 3);
-                    if (med.extinction[channel] != 0) v.rng.ctr++;
-                }
-                v.t = __hiloint2double(static_cast<int>(cur.hit.y), static_cast<int>(cur.hit.x));
-                v.point = org + v.dir * v.t;
-                v.obj = static_cast<int>(cur.ids.y);
-                v.prim = static_cast<int>(cur.ids.z);
-                v.next_medium = static_cast<int>(v.medium);
-                v.connect = false;
-                v.light_index = 0;
-                v.sh_dir = v3(0.0);
-                v.sh_contrib = v3(0.0);
-                v.sh_dist = 0;
-                v.sh_key = 0;
-                switch (cls) { // uniform over the block
-                    case 0: shade_vertex<0, TRIS, UV>(sc, res, med, v); break;
-                    case 1: shade_vertex<1, TRIS, UV>(sc, res, med, v); break;
-                    case 2: shade_vertex<2, TRIS, UV>(sc, res, med, v); break;
-                    case 3: shade_vertex<3, TRIS, UV>(sc, res, med, v); break;
-                    case 4: shade_vertex<4, TRIS, UV>(sc, res, med, v); break;
-                    case 5: shade_vertex<5, TRIS, UV>(sc, res, med, v); break;
-                    case 6: shade_vertex<6, TRIS, UV>(sc, res, med, v); break;
-                    default: shade_vertex<CLASS_SCATTER, TRIS, UV>(sc, res, med, v); break;
-                }
-
-                // Russian roulette :157-171
-                bool allow = true;
-                if (static_cast<int>(v.depth) >= sc.min_depth) {
-                    double threshold = fmin(vmax(v.thr), 0.9);
-                    allow = v.rng.u01() < threshold;
-                    if (allow) v.thr = v.thr / threshold;
-                }
-                const bool alive = allow && static_cast<int>(v.depth) + 1 <= sc.max_depth;
+                const bool alive = shade_record<TRIS, UV>(sc, b, res, cur, cls, v);
                 PTK_STAMP(0)
 
                 // request the next round's record and the list entry of the one after
                 if (have_next) nxt = load_record(in, src_next);
                 if (qi + 2 * BLOCK < n) src_after = list[first + qi + 2 * BLOCK];
 
-                // The shadow ray of the connection and the extension ray (the head of the next loop
-                // iteration: where does the new ray end) leave the vertex together.
-                const uint32_t medium_bits = v.next_medium < 0 ? MEDIUM_NONE : static_cast<uint32_t>(v.next_medium);
+                // the shadow ray of the connection and the extension ray leave the vertex together
                 double scatter_distance = INF;
-                if (alive) scatter_distance = free_flight_distance(sc, b, medium_bits, v.sid, v.rng.ctr);
-                HitInfo shadow_hit, extension_hit;
-                closest_hit_pair<TRIS>(sc, v.point, v.sh_dir, v.connect ? INF : -INF, shadow_hit, v.n_dir, alive ? scatter_distance : -INF,
-                                       extension_hit, st);
-                // compute_visibility (src/objects.cpp:470-513) and the acceptance test of sample_light
-                // (:558), on its own forked random-number stream
-                if (v.connect) {
-                    Rng march_rng{v.sh_key, 0};
-                    stat[2]++;
-                    stat[0]++;
-                    V3 visible = march_to_light<TRIS, UV>(sc, v.point, v.sh_dir, static_cast<int>(v.medium), v.light_index, v.sh_dist,
-                                                          march_rng, st, stat[0], shadow_hit);
-                    v.color = v.color + v.sh_contrib * visible;
-                }
+                if (alive) scatter_distance = free_flight_distance(sc, b, medium_bits_of(v), v.sid, v.rng.ctr);
+                vertex_rays<TRIS>(v, alive, scatter_distance, rays);
+                scan_objects<TRIS, DEFER ? MESH_DEFER : MESH_INLINE, 2>(sc, v.point, rays, st);
+                deferred = DEFER && (rays[0].needs_mesh || rays[1].needs_mesh);
+                origin = v.point;
+                if (!deferred) new_cls = finish_vertex<TRIS, UV>(sc, out, res, dst, v, alive, scatter_distance, rays[0].hit, rays[1].hit, st, stat);
                 PTK_STAMP(1)
-                Vertex nv;
-                nv.cls = -1;
-                if (alive) {
-                    stat[1]++;
-                    nv = vertex_of(extension_hit, scatter_distance);
-                    if (nv.cls < 0 && !sc.background_is_black) v.color = v.color + v.thr * v3(sc.background);
+            }
+            if (DEFER) { // queue the deferred vertices of this round and their rays: two atomics per block
+                const uint32_t my_rays = deferred ? (rays[0].needs_mesh ? 1u : 0u) + (rays[1].needs_mesh ? 1u : 0u) : 0u;
+                const unsigned long long vertex_mask = __ballot(deferred);
+                uint32_t rays_before = my_rays; // inclusive scan over the wave
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    uint32_t up = __shfl_up(rays_before, off);
+                    if ((threadIdx.x & 63) >= static_cast<uint32_t>(off)) rays_before += up;
                 }
-                PTK_STAMP(2)
-                new_cls = nv.cls;
-                if (nv.cls < 0) { // the path ended here
-                    flush_color(res, v.sid, v.color.x, v.color.y, v.color.z);
-                    out.cls[dst] = CLASS_DONE;
+                const int wave = threadIdx.x >> 6;
+                if ((threadIdx.x & 63) == 63) {
+                    queue_counts[wave][0] = rays_before;
+                    queue_counts[wave][1] = static_cast<uint32_t>(__popcll(vertex_mask));
                 }
-                else {
-                    stat[3]++;
-                    st2(out, PL_RAY0, dst, v.point.x, v.point.y);
-                    st2(out, PL_RAY1, dst, v.point.z, v.n_dir.x);
-                    st2(out, PL_RAY2, dst, v.n_dir.y, v.n_dir.z);
-                    st2(out, PL_THR0, dst, v.thr.x, v.thr.y);
-                    st2(out, PL_THR1, dst, v.thr.z, v.scatter_pdf);
-                    st2(out, PL_SAV0, dst, v.saved.x, v.saved.y);
-                    st2(out, PL_SAV1, dst, v.saved.z, v.color.x);
-                    st2(out, PL_COL, dst, v.color.y, v.color.z);
-                    stu4(out, PL_HIT, dst, static_cast<uint32_t>(__double2loint(nv.t)), static_cast<uint32_t>(__double2hiint(nv.t)),
-                         (v.depth + 1) | (v.ray_type << TYPE_SHIFT) | (v.has_hit ? FLAG_HAS_HIT : 0u) | (medium_bits << 16), v.sid);
-                    stu4(out, PL_IDS, dst, v.rng.ctr, static_cast<uint32_t>(nv.obj), static_cast<uint32_t>(nv.prim), 0u);
-                    out.cls[dst] = static_cast<uint8_t>(nv.cls);
+                __syncthreads();
+                if (threadIdx.x < 2) {
+                    uint32_t total = 0;
+                    for (int w = 0; w < BLOCK / 64; w++) total += queue_counts[w][threadIdx.x];
+                    queue_base[threadIdx.x] = total ? atomicAdd(queues.counters + threadIdx.x, total) : 0u;
                 }
+                __syncthreads();
+                if (deferred) {
+                    uint32_t ray_slot = queue_base[0] + rays_before - my_rays, vertex_slot = queue_base[1] + lanes_below(vertex_mask);
+                    for (int w = 0; w < wave; w++) {
+                        ray_slot += queue_counts[w][0];
+                        vertex_slot += queue_counts[w][1];
+                    }
+                    queues.vertices[vertex_slot] = DeferredVertex{dst, src, chunk, static_cast<uint32_t>(cls)};
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        if (rays[k].needs_mesh) {
+                            // t_max is the closest hit among the other objects: the walk starts culled
+                            queues.rays[ray_slot++] = RayRequest{origin.x, origin.y, origin.z, rays[k].dir.x, rays[k].dir.y, rays[k].dir.z,
+                                                                 rays[k].limit, 2 * dst + k, 0u};
+                        }
+                        else queues.results[2 * dst + k] = RayResult{INF, -1, 0};
+                    }
+                }
+                __syncthreads(); // queue_counts and queue_base are rewritten next round
             }
 #pragma unroll
             for (int c = 0; c < N_CLASSES; c++)
                 if ((sc.class_mask >> c) & 1u) my_counts[c] += static_cast<uint32_t>(__popcll(__ballot(new_cls == c)));
             cur = nxt;
+            src = src_next;
             src_next = src_after;
-            PTK_STAMP(3)
         }
+#ifdef PTK_STAMPS
+        stat[6] = st.nodes_visited; // per lane, summed over the block below
+        stat[7] = st.triangles_tested;
+        st.nodes_visited = st.triangles_tested = 0;
+#endif
         store_chunk_counts(wave_counts, my_counts, block_counts, count_stride, chunk);
-        add_block_statistics(statistics + static_cast<size_t>(cls) * N_STATISTICS * STATISTICS_SLOTS, wave_sums, stat);
+        add_block_statistics(statistics, wave_sums, stat);
     }
+}
+
+// Closest triangle for every queued ray, one ray per lane: the meshes of the scene in object order,
+// each hierarchy walked with the shrinking t_max.
+__global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_WAVES) void k_traverse(DevScene sc, DeferQueues queues,
+                                                                                           unsigned long long* statistics) {
+    __shared__ StackEntry lds_stack[LDS_STACK_DEPTH * BLOCK];
+    __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
+    TraversalStack st = make_stack(lds_stack);
+    const uint32_t n = queues.counters[0];
+    const PTK_CONSTANT DevShape* shapes = (const PTK_CONSTANT DevShape*) sc.shapes;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const RayRequest q = queues.rays[i];
+        const V3 org = v3(q.ox, q.oy, q.oz), dir = v3(q.dx, q.dy, q.dz);
+        const RayPrep rp = prepare_ray(dir);
+        RayResult best{q.limit, -1, 0};
+        for (int o = 0; o < sc.n_objects; o++) {
+            if (shapes[o].type != PTK_OBJ_MESH) continue;
+            int prim = -1;
+            mesh_closest_hit(sc, shapes[o].bvh_root, shapes[o].first_tri, org, dir, rp, best.t, prim, st);
+            if (prim >= 0) {
+                best.obj = o;
+                best.prim = prim;
+            }
+        }
+        queues.results[q.slot] = best;
+    }
+#ifdef PTK_STAMPS
+    uint32_t stat[N_STATISTICS] = {};
+    stat[6] = st.nodes_visited;
+    stat[7] = st.triangles_tested;
+    if (blockIdx.x * BLOCK < n) add_block_statistics(statistics, wave_sums, stat);
+#endif
+}
+
+// Finishes the deferred vertices: shades them again from the same records (same random numbers, so
+// the same two rays), scans the objects other than meshes, takes the closer of that hit and the
+// triangle k_traverse found, and goes on as k_bounce does.  The class counts go to the chunk the
+// vertex came from, by atomics (they are spread over as many addresses as there are chunks).
+template<bool UV>
+__global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_bounce_resume(DevScene sc, BatchParams b, PathPool in,
+                                                                                             PathPool out, SampleResults res,
+                                                                                             uint32_t* block_counts, uint32_t count_stride,
+                                                                                             unsigned long long* statistics,
+                                                                                             DeferQueues queues) {
+    __shared__ StackEntry lds_stack[LDS_STACK_DEPTH * BLOCK];
+    __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
+    TraversalStack st = make_stack(lds_stack);
+    const uint32_t n = queues.counters[1];
+    if (blockIdx.x * BLOCK >= n) return;
+    const PTK_CONSTANT DevShape* shapes = (const PTK_CONSTANT DevShape*) sc.shapes;
+    uint32_t stat[N_STATISTICS] = {};
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const DeferredVertex e = queues.vertices[i];
+        const Record cur = load_record(in, e.src);
+        PathVertex v;
+        const bool alive = shade_record<true, UV>(sc, b, res, cur, static_cast<int>(e.cls), v);
+        double scatter_distance = INF;
+        if (alive) scatter_distance = free_flight_distance(sc, b, medium_bits_of(v), v.sid, v.rng.ctr);
+        RayState rays[2];
+        vertex_rays<true>(v, alive, scatter_distance, rays);
+        scan_objects<true, MESH_SKIP, 2>(sc, v.point, rays, st);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const RayResult found = queues.results[2 * e.dst + k];
+            if (found.obj >= 0 && found.t < rays[k].hit.t) {
+                rays[k].hit.t = found.t;
+                rays[k].hit.obj = found.obj;
+                rays[k].hit.prim = found.prim;
+                rays[k].hit.cls = shapes[found.obj].cls;
+            }
+        }
+        const int new_cls = finish_vertex<true, UV>(sc, out, res, e.dst, v, alive, scatter_distance, rays[0].hit, rays[1].hit, st, stat);
+        if (new_cls >= 0) atomicAdd(block_counts + static_cast<size_t>(new_cls) * count_stride + e.chunk, 1u);
+    }
+    add_block_statistics(statistics, wave_sums, stat);
 }
 
 // Sums the per-block statistics slots into totals[N_STATISTICS]; one block.
@@ -906,17 +1063,32 @@ void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_
 
 void launch_bounce(hipStream_t s, uint32_t bound, uint32_t rounds, const DevScene& sc, const BatchParams& b, const PathPool& in,
                    const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info, uint32_t* block_counts,
-                   uint32_t count_stride, unsigned long long* statistics) {
+                   uint32_t count_stride, unsigned long long* statistics, const DeferQueues& queues) {
     const dim3 grid(min(chunk_blocks(bound, rounds), static_cast<uint32_t>(STATISTICS_SLOTS))), block(BLOCK);
-#define PTK_LAUNCH_BOUNCE(T, U) \
-    hipLaunchKernelGGL((k_bounce<T, U>), grid, block, 0, s, sc, b, in, out, res, list, info, rounds, block_counts, count_stride, statistics)
-    if (sc.has_triangles) {
-        if (sc.needs_uv) PTK_LAUNCH_BOUNCE(true, true);
-        else PTK_LAUNCH_BOUNCE(true, false);
+#define PTK_LAUNCH_BOUNCE(T, U, D)                                                                                                  \
+    hipLaunchKernelGGL((k_bounce<T, U, D>), grid, block, 0, s, sc, b, in, out, res, list, info, rounds, block_counts, count_stride, \
+                       statistics, queues)
+    if (sc.has_meshes) { // three passes: finish what misses every mesh, walk the hierarchies, finish the rest
+        (void) hipMemsetAsync(queues.counters, 0, 2 * sizeof(uint32_t), s);
+        if (sc.needs_uv) PTK_LAUNCH_BOUNCE(true, true, true);
+        else PTK_LAUNCH_BOUNCE(true, false, true);
+        const dim3 traverse_grid(min((2 * bound + BLOCK - 1) / BLOCK + 1, 16384u));
+        hipLaunchKernelGGL(k_traverse, traverse_grid, block, 0, s, sc, queues, statistics);
+        const dim3 resume_grid(min((bound + BLOCK - 1) / BLOCK + 1, static_cast<uint32_t>(STATISTICS_SLOTS)));
+        if (sc.needs_uv)
+            hipLaunchKernelGGL(k_bounce_resume<true>, resume_grid, block, 0, s, sc, b, in, out, res, block_counts, count_stride, statistics,
+                               queues);
+        else
+            hipLaunchKernelGGL(k_bounce_resume<false>, resume_grid, block, 0, s, sc, b, in, out, res, block_counts, count_stride,
+                               statistics, queues);
+    }
+    else if (sc.has_triangles) {
+        if (sc.needs_uv) PTK_LAUNCH_BOUNCE(true, true, false);
+        else PTK_LAUNCH_BOUNCE(true, false, false);
     }
     else {
-        if (sc.needs_uv) PTK_LAUNCH_BOUNCE(false, true);
-        else PTK_LAUNCH_BOUNCE(false, false);
+        if (sc.needs_uv) PTK_LAUNCH_BOUNCE(false, true, false);
+        else PTK_LAUNCH_BOUNCE(false, false, false);
     }
 #undef PTK_LAUNCH_BOUNCE
 }

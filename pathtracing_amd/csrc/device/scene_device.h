@@ -70,7 +70,8 @@ struct DevObject {
 // What the closest-hit loop reads per object: 128 bytes fetched by two scalar loads.
 //   sphere            f[0..2] centre, f[3] radius
 //   plane, rectangle  f[0..2] point, f[3..5] normal, f[6..8] axis 1, f[9..11] axis 2, f[12] L1, f[13] L2
-//   triangle, mesh    first_tri / bvh_root
+//   triangle          first_tri
+//   mesh              first_tri, bvh_root, f[0..5] bounds of the whole mesh (lo xyz, hi xyz)
 struct DevShape {
     double f[14];
     int32_t type;      // PTK_OBJ_*
@@ -101,8 +102,8 @@ struct BvhNode4 { // 128 bytes
 };
 constexpr int32_t BVH_EMPTY = INT32_MIN;
 // traversal stack: entries kept in LDS per lane, and in a private spill array beyond that
-constexpr int LDS_STACK_DEPTH = 24;
-constexpr int SPILL_STACK_DEPTH = 40;
+constexpr int LDS_STACK_DEPTH = 16;
+constexpr int SPILL_STACK_DEPTH = 48;
 
 struct DevCamera {
     double pos[3], view[3], screen_x[3], screen_y[3];
@@ -168,6 +169,34 @@ struct PathPool {
     uint8_t* cls;         // per record: class of the vertex to shade (0..7), or CLASS_DONE
 };
 // flags: depth (13 bits) | ray type << 13 | has_hit_surface << 15 | medium << 16
+
+// Scenes with meshes trace in three passes per bounce.  k_bounce finishes every vertex whose shadow
+// and extension rays miss the bounds of every mesh; the others it defers: it queues their rays
+// (with t_max already cut to the closest hit among the other objects) and the vertex itself.
+// k_traverse walks the hierarchies for the queued rays, one ray per lane, so that lanes and waves
+// are filled with rays that really traverse; k_bounce_resume shades the deferred vertices again (same
+// record, same random numbers, hence the same rays) and finishes them with the traversal results.
+struct RayRequest { // 64 bytes
+    double ox, oy, oz, dx, dy, dz;
+    double limit;   // t_max
+    uint32_t slot;  // 2 * record position in the output pool + (0 shadow ray, 1 extension ray)
+    uint32_t _pad;
+};
+struct RayResult { // 16 bytes; obj < 0: no triangle closer than the limit
+    double t;
+    int32_t obj, prim;
+};
+struct DeferredVertex { // 16 bytes
+    uint32_t dst, src; // record positions in the output and input pools
+    uint32_t chunk;    // chunk of the list it belongs to (its class count goes there)
+    uint32_t cls;
+};
+struct DeferQueues {
+    RayRequest* rays;
+    RayResult* results;       // [2 * capacity], indexed by RayRequest::slot
+    DeferredVertex* vertices;
+    uint32_t* counters;       // [0] rays queued, [1] vertices queued
+};
 
 // Per-sample results (PixelData, app/pathtracer.cpp:20-24), indexed by the sample's batch index
 // sid = sample * pixels_in_batch + pixel, so neighbouring lanes hold neighbouring pixels.

@@ -172,8 +172,9 @@ struct PtkScene {
     BinInfo* d_info = nullptr;  // [2]: summaries of the previous and the current bounce's lists
     BinInfo* h_info = nullptr;  // pinned ring of INFO_RING summaries read back asynchronously
     hipEvent_t info_events[8] = {};
-    unsigned long long* h_rays = nullptr; // pinned [N_CLASSES][N_STATISTICS]
-    unsigned long long* d_statistics = nullptr; // per class STATISTICS_SLOTS per-block slots, then per-class totals
+    unsigned long long* h_rays = nullptr; // pinned [N_STATISTICS]
+    unsigned long long* d_statistics = nullptr; // STATISTICS_SLOTS per-block slots, then the totals
+    DeferQueues queues{};       // scenes with meshes: rays and vertices waiting for k_traverse / k_bounce_resume
     std::vector<int> classes; // queue classes present in the scene
     PtkFilm* host_film = nullptr; // scratch film for ptk_render_host
     PtkStats stats{};
@@ -197,6 +198,12 @@ int ensure_capacity(PtkScene* s, int64_t paths) {
     s->results.plane_doubles = n * 2;
     HIP_TRY(b.alloc(&s->results.surface, n * 6));
     HIP_TRY(b.alloc(&s->list, n));
+    if (s->dev.has_meshes) {
+        HIP_TRY(b.alloc(&s->queues.rays, 2 * n));
+        HIP_TRY(b.alloc(&s->queues.results, 2 * n));
+        HIP_TRY(b.alloc(&s->queues.vertices, n));
+        HIP_TRY(b.alloc(&s->queues.counters, 2));
+    }
     s->count_stride = (chunk_capacity(static_cast<uint32_t>(n)) + 3u) & ~3u; // one entry per chunk; rows stay 16-byte aligned
     HIP_TRY(b.alloc(&s->block_counts, static_cast<size_t>(s->count_stride) * N_CLASSES));
     s->capacity = paths;
@@ -214,8 +221,8 @@ constexpr uint64_t BIN_BYTES_PER_RECORD = 1;                        // class in
 constexpr uint64_t BIN_BYTES_PER_VERTEX = 4;                        // list entry out
 constexpr uint64_t GENERATE_BYTES_PER_PATH = RECORD_BYTES + 1 + 3 * 16; // record, class, zeroed surface results out
 constexpr uint64_t ACCUMULATE_BYTES_PER_PATH = 32 + 3 * 16;         // results in
-// per-class statistics slots, then per-class totals
-constexpr size_t STATISTICS_VALUES = static_cast<size_t>(N_CLASSES) * N_STATISTICS * (STATISTICS_SLOTS + 1);
+// statistics slots, then the totals
+constexpr size_t STATISTICS_VALUES = static_cast<size_t>(N_STATISTICS) * (STATISTICS_SLOTS + 1);
 constexpr size_t STATISTICS_BYTES = STATISTICS_VALUES * sizeof(unsigned long long);
 
 struct EventTimer {
@@ -316,7 +323,7 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
         timer.begin(0);
         pool_rounds = chunk_rounds(bound);
         launch_bounce(g_stream, bound, pool_rounds, s->dev, b, current, next, s->results, s->list, info, s->block_counts,
-                      s->count_stride, s->d_statistics);
+                      s->count_stride, s->d_statistics, s->queues);
         timer.end();
         const int slot = launched % INFO_RING;
         HIP_TRY(hipMemcpyAsync(&s->h_info[slot], info, sizeof(BinInfo), hipMemcpyDeviceToHost, g_stream));
@@ -324,32 +331,23 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
         launched++;
         st.bounce_launch_rounds++;
         st.bin_launches += 2;
-        st.bounce_launches += 1;
+        st.bounce_launches += s->dev.has_meshes ? 3 : 1;
     }
-    unsigned long long* totals = s->d_statistics + static_cast<size_t>(N_CLASSES) * N_STATISTICS * STATISTICS_SLOTS;
-    for (int cls : s->classes)
-        launch_sum_statistics(g_stream, s->d_statistics + static_cast<size_t>(cls) * N_STATISTICS * STATISTICS_SLOTS,
-                              totals + cls * N_STATISTICS);
-    HIP_TRY(hipMemcpyAsync(s->h_rays, totals, N_CLASSES * N_STATISTICS * sizeof(unsigned long long), hipMemcpyDeviceToHost, g_stream));
+    unsigned long long* totals = s->d_statistics + static_cast<size_t>(N_STATISTICS) * STATISTICS_SLOTS;
+    launch_sum_statistics(g_stream, s->d_statistics, totals);
+    HIP_TRY(hipMemcpyAsync(s->h_rays, totals, N_STATISTICS * sizeof(unsigned long long), hipMemcpyDeviceToHost, g_stream));
     int rc = retire(true);
     if (rc != PTK_OK) return rc;
     HIP_TRY(hipStreamSynchronize(g_stream));
-    uint64_t segments = 0, extensions = b.n_paths, bounce_bytes = BOUNCE_BYTES_PER_PATH * b.n_paths;
-    for (int cls : s->classes) {
-        const unsigned long long* t = s->h_rays + cls * N_STATISTICS;
-        segments += t[0];
-        extensions += t[1];
-        const uint64_t continued = t[3], vertices = class_vertices[cls];
-        const uint64_t bytes = BOUNCE_BYTES_PER_VERTEX * vertices + BOUNCE_BYTES_PER_CONTINUED * continued +
-                               BOUNCE_BYTES_PER_ENDED * (vertices - continued);
-        st.class_vertices[cls] += vertices;
-        st.class_bytes[cls] += bytes;
-        bounce_bytes += bytes;
+    const uint64_t segments = s->h_rays[0], extensions = s->h_rays[1] + b.n_paths, continued = s->h_rays[3];
+    const uint64_t bounce_bytes = BOUNCE_BYTES_PER_PATH * b.n_paths + BOUNCE_BYTES_PER_VERTEX * sum_vertices +
+                                  BOUNCE_BYTES_PER_CONTINUED * continued + BOUNCE_BYTES_PER_ENDED * (sum_vertices - continued);
+    for (int c = 0; c < N_CLASSES; c++) st.class_vertices[c] += class_vertices[c];
 #ifdef PTK_STAMPS
-        std::fprintf(stderr, "class %d stamps (wave-cycles/16): shade %llu march %llu extend %llu store %llu; vertices %llu\n", cls, t[4], t[5],
-                     t[6], t[7], (unsigned long long) vertices);
+    std::fprintf(stderr, "wave-cycles/16: shade %llu, rays %llu; nodes visited %llu, triangles tested %llu; vertices %llu, rays %llu\n",
+                 s->h_rays[4], s->h_rays[5], s->h_rays[6], s->h_rays[7], (unsigned long long) sum_vertices,
+                 (unsigned long long) (segments + extensions));
 #endif
-    }
     st.shadow_rays += segments;
     st.extension_rays += extensions;
     st.vertices += sum_vertices;
@@ -718,6 +716,23 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
             sh.f[2] = o.pz;
             sh.f[3] = o.radius;
         }
+        else if (o.type == PTK_OBJ_MESH && o.bvh_root >= 0) { // bounds of the whole mesh = union of the root's children
+            const BvhNode4& root = nodes[static_cast<size_t>(o.bvh_root)];
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (int c = 0; c < 4; c++) {
+                if (root.child[c] == BVH_EMPTY) continue;
+                lo[0] = std::min(lo[0], static_cast<double>(root.lo_x[c]));
+                lo[1] = std::min(lo[1], static_cast<double>(root.lo_y[c]));
+                lo[2] = std::min(lo[2], static_cast<double>(root.lo_z[c]));
+                hi[0] = std::max(hi[0], static_cast<double>(root.hi_x[c]));
+                hi[1] = std::max(hi[1], static_cast<double>(root.hi_y[c]));
+                hi[2] = std::max(hi[2], static_cast<double>(root.hi_z[c]));
+            }
+            for (int a = 0; a < 3; a++) {
+                sh.f[a] = lo[a];
+                sh.f[3 + a] = hi[a];
+            }
+        }
         else if (o.type == PTK_OBJ_PLANE || o.type == PTK_OBJ_RECTANGLE) {
             const double v[14] = {o.px, o.py, o.pz, o.nx, o.ny, o.nz, o.v1x, o.v1y, o.v1z, o.v2x, o.v2y, o.v2z, o.L1, o.L2};
             std::memcpy(sh.f, v, sizeof(v));
@@ -760,7 +775,7 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     HIP_TRY(buf.alloc(&s->d_info, 2));
     HIP_TRY(buf.alloc(&s->d_statistics, STATISTICS_VALUES));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_info), INFO_RING * sizeof(BinInfo), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_rays), N_CLASSES * N_STATISTICS * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_rays), N_STATISTICS * sizeof(unsigned long long), hipHostMallocDefault));
     for (int i = 0; i < INFO_RING; i++) HIP_TRY(hipEventCreateWithFlags(&s->info_events[i], hipEventDisableTiming));
     *out = s.release();
     return PTK_OK;
