@@ -75,8 +75,11 @@ struct StackEntry {
     float tnear;
 };
 
+// The LDS address space is part of the pointer type: through a generic pointer the pushes and pops
+// would be flat instructions, which take the slower path of the vector memory unit.
+typedef __attribute__((address_space(3))) StackEntry LdsStackEntry;
 struct TraversalStack {
-    StackEntry* lds; // this thread's column: element d at lds[d * blockDim.x]
+    LdsStackEntry* lds; // this thread's column: element d at lds[d * blockDim.x]
     int stride;
     StackEntry spill[SPILL_STACK_DEPTH];
     int sp;
@@ -85,22 +88,28 @@ struct TraversalStack {
 #endif
     PTK_DEV void push(int32_t node, float tnear) {
         StackEntry e{node, tnear};
-        if (sp < LDS_STACK_DEPTH) lds[sp * stride] = e;
+        if (sp < LDS_STACK_DEPTH) {
+            lds[sp * stride].node = node;
+            lds[sp * stride].tnear = tnear;
+        }
         else if (sp < LDS_STACK_DEPTH + SPILL_STACK_DEPTH) spill[sp - LDS_STACK_DEPTH] = e;
         else return; // deeper than any tree the builder produces (its depth is bounded)
         sp++;
     }
     PTK_DEV StackEntry pop() {
         sp--;
-        return sp < LDS_STACK_DEPTH ? lds[sp * stride] : spill[sp - LDS_STACK_DEPTH];
+        if (sp < LDS_STACK_DEPTH) return StackEntry{lds[sp * stride].node, lds[sp * stride].tnear};
+        return spill[sp - LDS_STACK_DEPTH];
     }
 };
 
 // Closest triangle of one mesh.  Children are visited nearest first and skipped when their entry
 // distance is not below the best hit so far (Node::intersect, src/bvh.cpp:193-213); the slab test is
 // BoundingBox::intersect (:60-83) evaluated on the outward-rounded fp32 boxes.
+// any_hit: return at the first triangle found below t_best (enough for a shadow ray against a mesh
+// that no connection can pass through).
 PTK_DEV void mesh_closest_hit(const DevScene& sc, int32_t bvh_root, int64_t first_tri, const V3& org, const V3& dir,
-                              const RayPrep& rp, double& t_best, int& prim_best, TraversalStack& st) {
+                              const RayPrep& rp, double& t_best, int& prim_best, TraversalStack& st, bool any_hit = false) {
     if (bvh_root < 0) return;
     const double idx = 1.0 / dir.x, idy = 1.0 / dir.y, idz = 1.0 / dir.z;
     st.sp = 0;
@@ -122,6 +131,7 @@ PTK_DEV void mesh_closest_hit(const DevScene& sc, int32_t bvh_root, int64_t firs
                     prim_best = static_cast<int>(first + i);
                 }
             }
+            if (any_hit && prim_best >= 0) return;
             continue;
         }
 #ifdef PTK_STAMPS

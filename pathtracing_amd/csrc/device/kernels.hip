@@ -37,14 +37,14 @@ constexpr int BLOCK = 256;
 #define PTK_BOUNCE_WAVES 2
 #endif
 #ifndef PTK_TRAVERSE_WAVES
-#define PTK_TRAVERSE_WAVES 4
+#define PTK_TRAVERSE_WAVES 6
 #endif
 #define PTK_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 static_assert(BLOCK == BIN_BLOCK, "k_extend and the bin kernels share their block geometry");
 
 PTK_DEV TraversalStack make_stack(StackEntry* lds) {
     TraversalStack st;
-    st.lds = lds + threadIdx.x;
+    st.lds = (LdsStackEntry*) lds + threadIdx.x;
     st.stride = blockDim.x;
     st.sp = 0;
     return st;
@@ -843,10 +843,14 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_WAVES) void 
         for (int o = 0; o < sc.n_objects; o++) {
             if (shapes[o].type != PTK_OBJ_MESH) continue;
             int prim = -1;
-            mesh_closest_hit(sc, shapes[o].bvh_root, shapes[o].first_tri, org, dir, rp, best.t, prim, st);
+            // A shadow ray (even slot) is blocked by any triangle of a mesh that lets no connection
+            // through: the march ends in black whichever triangle it meets first.
+            const bool any_hit = (q.slot & 1u) == 0 && shapes[o].f[6] != 0;
+            mesh_closest_hit(sc, shapes[o].bvh_root, shapes[o].first_tri, org, dir, rp, best.t, prim, st, any_hit);
             if (prim >= 0) {
                 best.obj = o;
                 best.prim = prim;
+                if (any_hit) break;
             }
         }
         queues.results[q.slot] = best;

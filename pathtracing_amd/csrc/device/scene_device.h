@@ -71,7 +71,8 @@ struct DevObject {
 //   sphere            f[0..2] centre, f[3] radius
 //   plane, rectangle  f[0..2] point, f[3..5] normal, f[6..8] axis 1, f[9..11] axis 2, f[12] L1, f[13] L2
 //   triangle          first_tri
-//   mesh              first_tri, bvh_root, f[0..5] bounds of the whole mesh (lo xyz, hi xyz)
+//   mesh              first_tri, bvh_root, f[0..5] bounds of the whole mesh (lo xyz, hi xyz),
+//                     f[6] != 0: no connection to a light passes through this mesh
 struct DevShape {
     double f[14];
     int32_t type;      // PTK_OBJ_*
@@ -102,8 +103,11 @@ struct BvhNode4 { // 128 bytes
 };
 constexpr int32_t BVH_EMPTY = INT32_MIN;
 // traversal stack: entries kept in LDS per lane, and in a private spill array beyond that
-constexpr int LDS_STACK_DEPTH = 16;
-constexpr int SPILL_STACK_DEPTH = 48;
+#ifndef PTK_LDS_STACK
+#define PTK_LDS_STACK 12
+#endif
+constexpr int LDS_STACK_DEPTH = PTK_LDS_STACK;
+constexpr int SPILL_STACK_DEPTH = 64 - LDS_STACK_DEPTH;
 
 struct DevCamera {
     double pos[3], view[3], screen_x[3], screen_y[3];

@@ -732,6 +732,14 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
                 sh.f[a] = lo[a];
                 sh.f[3 + a] = hi[a];
             }
+            // Material::allow_direct_light (src/materials.cpp:55-60, :129-136) can only say yes through a
+            // transparency above zero or a Transparent material between media of equal refractive index;
+            // a light has to be found exactly (its distance is compared with the sampled point's).
+            const DevMaterial& m = o.mat;
+            auto ior = [&](int medium) { return medium >= 0 ? media[static_cast<size_t>(medium)].ior : 1.0; };
+            const bool passes = m.needs_uv || m.c_transparency > 0 ||
+                                (m.type == PTK_MAT_TRANSPARENT && ior(m.internal_medium) == ior(m.external_medium));
+            sh.f[6] = (!passes && !m.is_light) ? 1.0 : 0.0;
         }
         else if (o.type == PTK_OBJ_PLANE || o.type == PTK_OBJ_RECTANGLE) {
             const double v[14] = {o.px, o.py, o.pz, o.nx, o.ny, o.nz, o.v1x, o.v1y, o.v1z, o.v2x, o.v2y, o.v2z, o.L1, o.L2};
