@@ -144,7 +144,7 @@ def main():
     CLASS_NAMES = ["Diffuse", "Reflective", "Transparent", "Glossy", "MetallicMicrofacet", "ReflectiveMicrofacet",
                    "TransparentMicrofacet", "MediumScatter"]
     profiled = {"steps": 0}
-    fam = {"k_bounce": [0.0, 0, 0], "k_bin": [0.0, 0, 0]}  # ms, bytes, launches
+    fam = {"k_bounce": [0.0, 0, 0], "k_bin": [0.0, 0, 0], "k_traverse": [0.0, 0, 0]}  # ms, bytes, launches
     other_ms = [0.0]
 
     def step(i, timed=False):
@@ -156,7 +156,7 @@ def main():
             pt.set_profiling(False)
             s1 = scene.stats()
             profiled["steps"] += 1
-            for k, f in (("k_bounce", "bounce"), ("k_bin", "bin")):
+            for k, f in (("k_bounce", "bounce"), ("k_bin", "bin"), ("k_traverse", "traverse")):
                 fam[k][0] += getattr(s1, f + "_ms") - getattr(s0, f + "_ms")
                 fam[k][1] += getattr(s1, f + "_bytes") - getattr(s0, f + "_bytes")
                 fam[k][2] += getattr(s1, f + "_launches") - getattr(s0, f + "_launches")
@@ -192,9 +192,9 @@ def main():
     total_paths = paths_per_rank * world
     value = total_paths / elapsed / 1e6
 
-    # the dominant kernel: k_bounce (every path vertex: shading, shadow ray, extension ray), timed with HIP
-    # events on the library's stream over the profiled steps of this timed region; named as rocprofv3 shows it
-    d_ms, d_bytes, d_launches = fam["k_bounce"]
+    # The dominant kernel, timed with HIP events on the library's stream over the profiled steps of this timed
+    # region and named as rocprofv3 shows it: k_bounce (every path vertex: shading, shadow ray, extension ray; in
+    # scenes with meshes its time includes the resume pass) or, in scenes with meshes, k_traverse.
     hs = host_scene.desc
     tris = "true" if hs.n_triangles > 0 else "false"
 
@@ -204,7 +204,12 @@ def main():
                        for m in (hs.materials[k].albedo_map, hs.materials[k].emission_color_map, hs.materials[k].light_intensity_map,
                                  hs.materials[k].roughness_map, hs.materials[k].transparency_map)) else "false"
     defer = "true" if any(hs.objects[i].type == pt._ffi.PTK_OBJ_MESH for i in range(hs.n_objects)) else "false"
-    kernel = f"ptk::k_bounce<{tris}, {uv}, {defer}>"
+    if fam["k_traverse"][0] > fam["k_bounce"][0]:
+        kernel = "ptk::k_traverse"
+        d_ms, d_bytes, d_launches = fam["k_traverse"]
+    else:
+        kernel = f"ptk::k_bounce<{tris}, {uv}, {defer}>"
+        d_ms, d_bytes, d_launches = fam["k_bounce"]
     achieved = d_bytes / (d_ms * 1e-3) / 1e9 if d_ms > 0 else 0.0
     traffic = None
     traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -219,7 +224,8 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_launch": d_bytes / max(d_launches, 1), "ms_per_launch": d_ms / max(d_launches, 1),
                 "launches": int(d_launches), "profiled_steps": profiled["steps"],
-                "device_ms": {"k_bounce": fam["k_bounce"][0], "k_bin": fam["k_bin"][0], "other": other_ms[0]},
+                "device_ms": {"k_bounce": fam["k_bounce"][0], "k_bin": fam["k_bin"][0], "k_traverse": fam["k_traverse"][0],
+                              "other": other_ms[0]},
                 "vertices_by_class": vertices_by_class}
 
     out = {
@@ -234,7 +240,10 @@ def main():
                  "extension_rays_per_path": st.extension_rays / max(st.paths, 1),
                  "shadow_rays_per_path": st.shadow_rays / max(st.paths, 1),
                  "vertices_per_path": st.vertices / max(st.paths, 1),
-                 "algorithmic_bytes_per_path": st.algorithmic_bytes / max(st.paths, 1)},
+                 "algorithmic_bytes_per_path": st.algorithmic_bytes / max(st.paths, 1),
+                 "traversed_rays_per_path": st.traversed_rays / max(st.paths, 1),
+                 "nodes_per_traversed_ray": st.nodes_visited / max(st.traversed_rays, 1),
+                 "triangles_per_traversed_ray": st.triangles_tested / max(st.traversed_rays, 1)},
         "roofline": roofline,
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:

@@ -187,13 +187,15 @@ typedef struct PtkStats {
     uint64_t vertices;      /* surface + scatter vertices shaded */
     uint64_t bounce_launch_rounds;
     uint64_t algorithmic_bytes; /* path-state/queue bytes the kernels are specified to move */
-    /* Kernel families: bounce = the per-material kernels (shading, shadow ray and extension ray of
-     * one path vertex), bin = the class sort between bounces. */
-    double bounce_ms, bin_ms, other_ms, reserved_ms; /* device time per family, HIP events, while profiling is on */
-    uint64_t bounce_launches, bin_launches, reserved_launches;
-    uint64_t bounce_bytes, bin_bytes, reserved_bytes; /* algorithmic bytes per family */
+    /* Kernel families: bounce = k_bounce and k_bounce_resume (shading, shadow ray and extension ray
+     * of one path vertex), bin = the class sort between bounces, traverse = the hierarchy walks of
+     * scenes with meshes (k_traverse). */
+    double bounce_ms, bin_ms, other_ms, traverse_ms; /* device time per family, HIP events, while profiling is on */
+    uint64_t bounce_launches, bin_launches, traverse_launches;
+    uint64_t bounce_bytes, bin_bytes, traverse_bytes; /* algorithmic bytes per family */
     /* Vertices shaded per class (PTK_MAT_* order, then medium scattering). */
     uint64_t class_vertices[8];
+    uint64_t traversed_rays, nodes_visited, triangles_tested; /* k_traverse */
 } PtkStats;
 
 /* Selects the GPU for this process (hipSetDevice) and creates the library's stream.

@@ -66,9 +66,10 @@ class PtkStats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("extension_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("vertices", C.c_uint64), ("bounce_launch_rounds", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
                 ("bounce_ms", C.c_double), ("bin_ms", C.c_double), ("other_ms", C.c_double),
-                ("reserved_ms", C.c_double), ("bounce_launches", C.c_uint64), ("bin_launches", C.c_uint64),
-                ("reserved_launches", C.c_uint64), ("bounce_bytes", C.c_uint64), ("bin_bytes", C.c_uint64),
-                ("reserved_bytes", C.c_uint64), ("class_vertices", C.c_uint64 * 8)]
+                ("traverse_ms", C.c_double), ("bounce_launches", C.c_uint64), ("bin_launches", C.c_uint64),
+                ("traverse_launches", C.c_uint64), ("bounce_bytes", C.c_uint64), ("bin_bytes", C.c_uint64),
+                ("traverse_bytes", C.c_uint64), ("class_vertices", C.c_uint64 * 8), ("traversed_rays", C.c_uint64),
+                ("nodes_visited", C.c_uint64), ("triangles_tested", C.c_uint64)]
 
 
 class PtkDenoiseTask(C.Structure):

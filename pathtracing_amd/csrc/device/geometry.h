@@ -83,9 +83,7 @@ struct TraversalStack {
     int stride;
     StackEntry spill[SPILL_STACK_DEPTH];
     int sp;
-#ifdef PTK_STAMPS
-    uint32_t nodes_visited = 0, triangles_tested = 0; // profiling build
-#endif
+    uint32_t nodes_visited = 0, triangles_tested = 0; // statistics of k_traverse
     PTK_DEV void push(int32_t node, float tnear) {
         StackEntry e{node, tnear};
         if (sp < LDS_STACK_DEPTH) {
@@ -121,9 +119,7 @@ PTK_DEV void mesh_closest_hit(const DevScene& sc, int32_t bvh_root, int64_t firs
             uint32_t code = static_cast<uint32_t>(~e.node);
             int64_t first = first_tri + (code >> 3);
             int count = static_cast<int>(code & 7u) + 1;
-#ifdef PTK_STAMPS
             st.triangles_tested += count;
-#endif
             for (int i = 0; i < count; i++) {
                 double d;
                 if (triangle_hit(sc.tri_hot[first + i], org, rp, t_best, d) && d > EPSILON && d < t_best) {
@@ -134,9 +130,7 @@ PTK_DEV void mesh_closest_hit(const DevScene& sc, int32_t bvh_root, int64_t firs
             if (any_hit && prim_best >= 0) return;
             continue;
         }
-#ifdef PTK_STAMPS
         st.nodes_visited++;
-#endif
         const BvhNode4& n = sc.nodes[e.node];
         float tn[4];
         int32_t ch[4];

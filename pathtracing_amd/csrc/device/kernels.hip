@@ -816,11 +816,6 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
             src = src_next;
             src_next = src_after;
         }
-#ifdef PTK_STAMPS
-        stat[6] = st.nodes_visited; // per lane, summed over the block below
-        stat[7] = st.triangles_tested;
-        st.nodes_visited = st.triangles_tested = 0;
-#endif
         store_chunk_counts(wave_counts, my_counts, block_counts, count_stride, chunk);
         add_block_statistics(statistics, wave_sums, stat);
     }
@@ -834,12 +829,15 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_WAVES) void 
     __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
     TraversalStack st = make_stack(lds_stack);
     const uint32_t n = queues.counters[0];
+    if (blockIdx.x * BLOCK >= n) return;
     const PTK_CONSTANT DevShape* shapes = (const PTK_CONSTANT DevShape*) sc.shapes;
+    uint32_t stat[N_STATISTICS] = {}; // [0] rays, [1] nodes visited, [2] triangles tested
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         const RayRequest q = queues.rays[i];
         const V3 org = v3(q.ox, q.oy, q.oz), dir = v3(q.dx, q.dy, q.dz);
         const RayPrep rp = prepare_ray(dir);
         RayResult best{q.limit, -1, 0};
+        stat[0]++;
         for (int o = 0; o < sc.n_objects; o++) {
             if (shapes[o].type != PTK_OBJ_MESH) continue;
             int prim = -1;
@@ -855,12 +853,9 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_WAVES) void 
         }
         queues.results[q.slot] = best;
     }
-#ifdef PTK_STAMPS
-    uint32_t stat[N_STATISTICS] = {};
-    stat[6] = st.nodes_visited;
-    stat[7] = st.triangles_tested;
-    if (blockIdx.x * BLOCK < n) add_block_statistics(statistics, wave_sums, stat);
-#endif
+    stat[1] = st.nodes_visited;
+    stat[2] = st.triangles_tested;
+    add_block_statistics(statistics, wave_sums, stat);
 }
 
 // Finishes the deferred vertices: shades them again from the same records (same random numbers, so
@@ -1072,19 +1067,10 @@ void launch_bounce(hipStream_t s, uint32_t bound, uint32_t rounds, const DevScen
 #define PTK_LAUNCH_BOUNCE(T, U, D)                                                                                                  \
     hipLaunchKernelGGL((k_bounce<T, U, D>), grid, block, 0, s, sc, b, in, out, res, list, info, rounds, block_counts, count_stride, \
                        statistics, queues)
-    if (sc.has_meshes) { // three passes: finish what misses every mesh, walk the hierarchies, finish the rest
+    if (sc.has_meshes) {
         (void) hipMemsetAsync(queues.counters, 0, 2 * sizeof(uint32_t), s);
         if (sc.needs_uv) PTK_LAUNCH_BOUNCE(true, true, true);
         else PTK_LAUNCH_BOUNCE(true, false, true);
-        const dim3 traverse_grid(min((2 * bound + BLOCK - 1) / BLOCK + 1, 16384u));
-        hipLaunchKernelGGL(k_traverse, traverse_grid, block, 0, s, sc, queues, statistics);
-        const dim3 resume_grid(min((bound + BLOCK - 1) / BLOCK + 1, static_cast<uint32_t>(STATISTICS_SLOTS)));
-        if (sc.needs_uv)
-            hipLaunchKernelGGL(k_bounce_resume<true>, resume_grid, block, 0, s, sc, b, in, out, res, block_counts, count_stride, statistics,
-                               queues);
-        else
-            hipLaunchKernelGGL(k_bounce_resume<false>, resume_grid, block, 0, s, sc, b, in, out, res, block_counts, count_stride,
-                               statistics, queues);
     }
     else if (sc.has_triangles) {
         if (sc.needs_uv) PTK_LAUNCH_BOUNCE(true, true, false);
@@ -1095,6 +1081,21 @@ void launch_bounce(hipStream_t s, uint32_t bound, uint32_t rounds, const DevScen
         else PTK_LAUNCH_BOUNCE(false, false, false);
     }
 #undef PTK_LAUNCH_BOUNCE
+}
+
+void launch_traverse(hipStream_t s, uint32_t bound, const DevScene& sc, const DeferQueues& queues, unsigned long long* statistics) {
+    const dim3 grid(min((2 * bound + BLOCK - 1) / BLOCK + 1, static_cast<uint32_t>(STATISTICS_SLOTS)));
+    hipLaunchKernelGGL(k_traverse, grid, dim3(BLOCK), 0, s, sc, queues, statistics);
+}
+
+void launch_bounce_resume(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
+                          const SampleResults& res, uint32_t* block_counts, uint32_t count_stride, unsigned long long* statistics,
+                          const DeferQueues& queues) {
+    const dim3 grid(min((bound + BLOCK - 1) / BLOCK + 1, static_cast<uint32_t>(STATISTICS_SLOTS))), block(BLOCK);
+    if (sc.needs_uv)
+        hipLaunchKernelGGL(k_bounce_resume<true>, grid, block, 0, s, sc, b, in, out, res, block_counts, count_stride, statistics, queues);
+    else
+        hipLaunchKernelGGL(k_bounce_resume<false>, grid, block, 0, s, sc, b, in, out, res, block_counts, count_stride, statistics, queues);
 }
 
 void launch_sum_statistics(hipStream_t s, const unsigned long long* slots, unsigned long long* totals) {

@@ -172,7 +172,7 @@ struct PtkScene {
     BinInfo* d_info = nullptr;  // [2]: summaries of the previous and the current bounce's lists
     BinInfo* h_info = nullptr;  // pinned ring of INFO_RING summaries read back asynchronously
     hipEvent_t info_events[8] = {};
-    unsigned long long* h_rays = nullptr; // pinned [N_STATISTICS]
+    unsigned long long* h_rays = nullptr; // pinned [2][N_STATISTICS]
     unsigned long long* d_statistics = nullptr; // STATISTICS_SLOTS per-block slots, then the totals
     DeferQueues queues{};       // scenes with meshes: rays and vertices waiting for k_traverse / k_bounce_resume
     std::vector<int> classes; // queue classes present in the scene
@@ -221,8 +221,10 @@ constexpr uint64_t BIN_BYTES_PER_RECORD = 1;                        // class in
 constexpr uint64_t BIN_BYTES_PER_VERTEX = 4;                        // list entry out
 constexpr uint64_t GENERATE_BYTES_PER_PATH = RECORD_BYTES + 1 + 3 * 16; // record, class, zeroed surface results out
 constexpr uint64_t ACCUMULATE_BYTES_PER_PATH = 32 + 3 * 16;         // results in
-// statistics slots, then the totals
-constexpr size_t STATISTICS_VALUES = static_cast<size_t>(N_STATISTICS) * (STATISTICS_SLOTS + 1);
+constexpr uint64_t TRAVERSE_BYTES_PER_RAY = sizeof(RayRequest) + sizeof(RayResult);
+// two sets of statistics slots (k_bounce and k_bounce_resume; k_traverse), then their totals
+constexpr size_t STATISTICS_SET = static_cast<size_t>(N_STATISTICS) * STATISTICS_SLOTS;
+constexpr size_t STATISTICS_VALUES = 2 * (STATISTICS_SET + N_STATISTICS);
 constexpr size_t STATISTICS_BYTES = STATISTICS_VALUES * sizeof(unsigned long long);
 
 struct EventTimer {
@@ -258,6 +260,7 @@ struct EventTimer {
             switch (sp.first) {
                 case 0: s->stats.bounce_ms += ms; break;
                 case 1: s->stats.bin_ms += ms; break;
+                case 3: s->stats.traverse_ms += ms; break;
                 default: s->stats.other_ms += ms; break;
             }
         }
@@ -325,17 +328,28 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
         launch_bounce(g_stream, bound, pool_rounds, s->dev, b, current, next, s->results, s->list, info, s->block_counts,
                       s->count_stride, s->d_statistics, s->queues);
         timer.end();
+        if (s->dev.has_meshes) { // finish what misses every mesh above, walk the hierarchies, finish the rest
+            timer.begin(3);
+            launch_traverse(g_stream, bound, s->dev, s->queues, s->d_statistics + STATISTICS_SET);
+            timer.end();
+            timer.begin(0);
+            launch_bounce_resume(g_stream, bound, s->dev, b, current, next, s->results, s->block_counts, s->count_stride, s->d_statistics,
+                                 s->queues);
+            timer.end();
+            st.traverse_launches++;
+        }
         const int slot = launched % INFO_RING;
         HIP_TRY(hipMemcpyAsync(&s->h_info[slot], info, sizeof(BinInfo), hipMemcpyDeviceToHost, g_stream));
         HIP_TRY(hipEventRecord(s->info_events[slot], g_stream));
         launched++;
         st.bounce_launch_rounds++;
         st.bin_launches += 2;
-        st.bounce_launches += s->dev.has_meshes ? 3 : 1;
+        st.bounce_launches += s->dev.has_meshes ? 2 : 1;
     }
-    unsigned long long* totals = s->d_statistics + static_cast<size_t>(N_STATISTICS) * STATISTICS_SLOTS;
+    unsigned long long* totals = s->d_statistics + 2 * STATISTICS_SET;
     launch_sum_statistics(g_stream, s->d_statistics, totals);
-    HIP_TRY(hipMemcpyAsync(s->h_rays, totals, N_STATISTICS * sizeof(unsigned long long), hipMemcpyDeviceToHost, g_stream));
+    if (s->dev.has_meshes) launch_sum_statistics(g_stream, s->d_statistics + STATISTICS_SET, totals + N_STATISTICS);
+    HIP_TRY(hipMemcpyAsync(s->h_rays, totals, 2 * N_STATISTICS * sizeof(unsigned long long), hipMemcpyDeviceToHost, g_stream));
     int rc = retire(true);
     if (rc != PTK_OK) return rc;
     HIP_TRY(hipStreamSynchronize(g_stream));
@@ -344,10 +358,18 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
                                   BOUNCE_BYTES_PER_CONTINUED * continued + BOUNCE_BYTES_PER_ENDED * (sum_vertices - continued);
     for (int c = 0; c < N_CLASSES; c++) st.class_vertices[c] += class_vertices[c];
 #ifdef PTK_STAMPS
-    std::fprintf(stderr, "wave-cycles/16: shade %llu, rays %llu; nodes visited %llu, triangles tested %llu; vertices %llu, rays %llu\n",
-                 s->h_rays[4], s->h_rays[5], s->h_rays[6], s->h_rays[7], (unsigned long long) sum_vertices,
-                 (unsigned long long) (segments + extensions));
+    std::fprintf(stderr, "wave-cycles/16: shade %llu, rays %llu; vertices %llu, rays %llu\n", s->h_rays[4], s->h_rays[5],
+                 (unsigned long long) sum_vertices, (unsigned long long) (segments + extensions));
 #endif
+    if (s->dev.has_meshes) { // k_traverse: ray request in, result out, 128-byte nodes, 72-byte triangle vertices
+        const unsigned long long* t = s->h_rays + N_STATISTICS;
+        const uint64_t tb = TRAVERSE_BYTES_PER_RAY * t[0] + sizeof(BvhNode4) * t[1] + sizeof(TriHot) * t[2];
+        st.traversed_rays += t[0];
+        st.nodes_visited += t[1];
+        st.triangles_tested += t[2];
+        st.traverse_bytes += tb;
+        st.algorithmic_bytes += tb;
+    }
     st.shadow_rays += segments;
     st.extension_rays += extensions;
     st.vertices += sum_vertices;
@@ -783,7 +805,7 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     HIP_TRY(buf.alloc(&s->d_info, 2));
     HIP_TRY(buf.alloc(&s->d_statistics, STATISTICS_VALUES));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_info), INFO_RING * sizeof(BinInfo), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_rays), N_STATISTICS * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_rays), 2 * N_STATISTICS * sizeof(unsigned long long), hipHostMallocDefault));
     for (int i = 0; i < INFO_RING; i++) HIP_TRY(hipEventCreateWithFlags(&s->info_events[i], hipEventDisableTiming));
     *out = s.release();
     return PTK_OK;
