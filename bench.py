@@ -93,7 +93,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    # PTK_BENCH_FORCE_DISTRIBUTED=1 takes the multi-GPU path (torch tensors, RCCL all-reduce) with any world
+    # size, so that it can be rehearsed on a one-GPU box
+    distributed = world > 1 or os.environ.get("PTK_BENCH_FORCE_DISTRIBUTED") == "1"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import torch

@@ -1,0 +1,45 @@
+"""bench.py on a GPU box: the output contract, and the multi-GPU code path rehearsed with one rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--width", "320", "--height", "180", "--steps", "5", "--warmup", "1", "--cpu-threads", "4"]
+
+
+def check_line(out, n_gpus):
+    line = [l for l in out.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == n_gpus and d["steps"] == 5 and d["warmup"] == 1
+    assert d["unit"] == "Mpaths/s" and d["value"] > 0 and d["scaling"] == "weak" and d["dtype"] == "f64"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["kernel"].startswith("ptk::k_") and r["profiled_steps"] >= 1
+    return d
+
+
+def test_default_path_prints_the_contract_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = check_line(r.stdout, 1)
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 4 and c["value"] > 0 and c["unit"] == "Mpaths/s" and c["sample"]
+
+
+def test_multi_gpu_path_with_one_rank():
+    env = dict(os.environ, PTK_BENCH_FORCE_DISTRIBUTED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline"] + SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = check_line(r.stdout, 1)
+    assert d["cpu_baseline"] is None
