@@ -262,6 +262,11 @@ int ptk_reset_stats(PtkScene* scene);
  * when enabled, HIP events bracket every kernel family on the library's stream and the
  * *_ms fields of PtkStats accumulate device time.  Also enabled by PTK_PROFILE=1. */
 int ptk_set_profiling(int enabled);
+/* Tuning knobs, by name (no counterpart in the reference).  "tail_records": once at most this many paths of a
+ * batch are left, one kernel launch follows each of them to its end instead of running three launches per bounce
+ * (0 switches that off; default and upper limit 131072).  Unknown names and values out of range fail with
+ * PTK_ERR_INVALID.  Results do not depend on any knob. */
+int ptk_set_option(const char* name, int64_t value);
 
 /* ---- denoise ---------------------------------------------------------------------- */
 

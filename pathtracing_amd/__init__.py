@@ -181,6 +181,11 @@ def sync():
     _check_dev(device_lib().ptk_sync())
 
 
+def set_option(name, value):
+    """Tuning knobs of the device library (include/ptk.h, ptk_set_option); results never depend on them."""
+    _check_dev(device_lib().ptk_set_option(name.encode(), int(value)))
+
+
 def set_profiling(enabled):
     """HIP-event timing of every kernel family into PtkStats.*_ms (costs a few microseconds per launch)."""
     _check_dev(device_lib().ptk_set_profiling(1 if enabled else 0))

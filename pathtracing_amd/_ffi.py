@@ -128,6 +128,7 @@ DEVICE_PROTOTYPES = {
     "ptk_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PtkStats)]),
     "ptk_reset_stats": (C.c_int, [C.c_void_p]),
     "ptk_set_profiling": (C.c_int, [C.c_int]),
+    "ptk_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
     "ptk_denoise": (C.c_int, [C.POINTER(PtkDenoiseTask), C.c_int32, C.c_int32, C.c_int32, dptr, dptr, dptr]),
     "ptk_denoise_device": (C.c_int, [C.POINTER(PtkDenoiseTask), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -30,6 +30,10 @@ void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_
 void launch_bounce(hipStream_t s, uint32_t bound, uint32_t rounds, const DevScene& sc, const BatchParams& b, const PathPool& in,
                    const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info, uint32_t* block_counts,
                    uint32_t count_stride, unsigned long long* statistics, const DeferQueues& queues);
+// Every remaining bounce of the paths in `list` (at most `bound` of them, bound <= TAIL_RECORDS) in one launch.
+constexpr uint32_t TAIL_RECORDS = 131072;
+void launch_tail(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
+                 const SampleResults& res, const uint32_t* list, const BinInfo* info, unsigned long long* statistics);
 // Scenes with meshes, after launch_bounce: the hierarchy walks of the queued rays (statistics slots: [0] rays,
 // [1] nodes visited, [2] triangles tested), then the deferred vertices.
 void launch_traverse(hipStream_t s, uint32_t bound, const DevScene& sc, const DeferQueues& queues, unsigned long long* statistics);

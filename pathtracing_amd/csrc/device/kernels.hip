@@ -11,6 +11,7 @@
 //                  closest hit of the new ray (the next loop head + find_closest_hit); reads the
 //                  record through the list and writes the updated record, with the class of its
 //                  next vertex, to the other pool at the list position; counts the classes it wrote
+//   k_tail         the last bounces of a batch: one lane follows one path to its end, no sorting
 //   k_accumulate   per-pixel sample means folded into the film  (compute_pixel_color's division and
 //                  increment_average)
 //
@@ -128,7 +129,8 @@ PTK_DEV double2* surface_plane(const SampleResults& res, int plane) {
 
 // Statistics without atomics on shared lines: every block adds its totals to its own slot.
 // values: [0] visibility-march segments, [1] extension rays, [2] connections marched,
-// [3] records written for the next bounce.
+// [3] records written for the next bounce, [4] vertices shaded by k_tail after its first round,
+// [5] unused, [6] and [7] cycle stamps of the sections of k_bounce in the -DPTK_STAMPS build.
 PTK_DEV void add_block_statistics(unsigned long long* slots, uint32_t (*wave_sums)[N_STATISTICS], uint32_t* mine) {
 #pragma unroll
     for (int k = 0; k < N_STATISTICS; k++)
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
 #define PTK_STAMP(k)                                                                                   \
     {                                                                                                  \
         const uint64_t now_ = __builtin_readcyclecounter();                                            \
-        if ((threadIdx.x & 63) == 0) stat[4 + (k)] += static_cast<uint32_t>((now_ - stamp_) >> 4);     \
+        if ((threadIdx.x & 63) == 0) stat[6 + (k)] += static_cast<uint32_t>((now_ - stamp_) >> 4);     \
         stamp_ = now_;                                                                                 \
     }
     uint64_t stamp_ = __builtin_readcyclecounter();
@@ -819,6 +821,42 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
         store_chunk_counts(wave_counts, my_counts, block_counts, count_stride, chunk);
         add_block_statistics(statistics, wave_sums, stat);
     }
+}
+
+// The last bounces of a batch, when few paths are left: one lane follows one path to its end,
+// without the class sort between bounces (the class switch is per lane here, which costs nothing
+// at this size), so the tail of the path-length distribution costs one launch instead of three per
+// bounce.  Same per-vertex code as k_bounce, hence the same results.  Round 0 reads record list[i] of
+// `in` and writes record i of `out`; later rounds update record i of `out` in place.
+template<bool TRIS, bool UV>
+__global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_tail(DevScene sc, BatchParams b, PathPool in, PathPool out,
+                                                                                    SampleResults res, const uint32_t* list,
+                                                                                    const BinInfo* info, unsigned long long* statistics) {
+    __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1];
+    __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
+    TraversalStack st = make_stack(lds_stack);
+    const uint32_t n = info->total;
+    if (blockIdx.x * BLOCK >= n) return;
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t stat[N_STATISTICS] = {};
+    if (i < n) {
+        const uint32_t first_src = list[i];
+        int cls = in.cls[first_src];
+        for (int round = 0; cls >= 0; round++) {
+            const Record cur = round == 0 ? load_record(in, first_src) : load_record(out, i);
+            PathVertex v;
+            const bool alive = shade_record<TRIS, UV>(sc, b, res, cur, cls, v);
+            if (round > 0) stat[4]++;
+            double scatter_distance = INF;
+            if (alive) scatter_distance = free_flight_distance(sc, b, medium_bits_of(v), v.sid, v.rng.ctr);
+            RayState rays[2];
+            vertex_rays<TRIS>(v, alive, scatter_distance, rays);
+            scan_objects<TRIS, MESH_INLINE, 2>(sc, v.point, rays, st);
+            cls = finish_vertex<TRIS, UV>(sc, out, res, i, v, alive, scatter_distance, rays[0].hit, rays[1].hit, st, stat);
+            __threadfence(); // the record written above is read back by the next round
+        }
+    }
+    add_block_statistics(statistics, wave_sums, stat);
 }
 
 // Closest triangle for every queued ray, one ray per lane: the meshes of the scene in object order,
@@ -1081,6 +1119,21 @@ void launch_bounce(hipStream_t s, uint32_t bound, uint32_t rounds, const DevScen
         else PTK_LAUNCH_BOUNCE(false, false, false);
     }
 #undef PTK_LAUNCH_BOUNCE
+}
+
+void launch_tail(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
+                 const SampleResults& res, const uint32_t* list, const BinInfo* info, unsigned long long* statistics) {
+    const dim3 grid((bound + BLOCK - 1) / BLOCK + 1), block(BLOCK);
+#define PTK_LAUNCH_TAIL(T, U) hipLaunchKernelGGL((k_tail<T, U>), grid, block, 0, s, sc, b, in, out, res, list, info, statistics)
+    if (sc.has_triangles) {
+        if (sc.needs_uv) PTK_LAUNCH_TAIL(true, true);
+        else PTK_LAUNCH_TAIL(true, false);
+    }
+    else {
+        if (sc.needs_uv) PTK_LAUNCH_TAIL(false, true);
+        else PTK_LAUNCH_TAIL(false, false);
+    }
+#undef PTK_LAUNCH_TAIL
 }
 
 void launch_traverse(hipStream_t s, uint32_t bound, const DevScene& sc, const DeferQueues& queues, unsigned long long* statistics) {

@@ -141,11 +141,7 @@ struct DevScene {
     uint32_t class_mask;                 // material classes present in the scene (+ scatter bit)
 };
 
-#ifdef PTK_STAMPS
-constexpr int N_STATISTICS = 8;         // + cycle stamps of the sections of k_bounce (profiling build)
-#else
-constexpr int N_STATISTICS = 4;         // values per statistics slot (see kernels.hip)
-#endif
+constexpr int N_STATISTICS = 8;         // values per statistics slot (see kernels.hip)
 constexpr int STATISTICS_SLOTS = 8192; // per-block slots = the largest k_bounce grid
 
 // Path records live in two pools used ping-pong.  A pool is a set of planes of 16-byte elements

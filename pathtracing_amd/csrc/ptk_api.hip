@@ -26,6 +26,7 @@ thread_local std::string g_error;
 hipStream_t g_stream = nullptr;
 int g_device = -1;
 bool g_profiling = false;
+uint32_t g_tail_records = TAIL_RECORDS;
 
 int fail(int code, const std::string& message) {
     g_error = message;
@@ -323,6 +324,19 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
         timer.begin(1);
         launch_bin(g_stream, s->dev, current, bound, pool_rounds, previous, s->block_counts, s->count_stride, info, s->list);
         timer.end();
+        if (bound <= g_tail_records) { // few paths left: one launch follows every one of them to its end
+            timer.begin(0);
+            launch_tail(g_stream, bound, s->dev, b, current, next, s->results, s->list, info, s->d_statistics);
+            timer.end();
+            const int slot = launched % INFO_RING;
+            HIP_TRY(hipMemcpyAsync(&s->h_info[slot], info, sizeof(BinInfo), hipMemcpyDeviceToHost, g_stream));
+            HIP_TRY(hipEventRecord(s->info_events[slot], g_stream));
+            launched++;
+            st.bounce_launch_rounds++;
+            st.bin_launches += 2;
+            st.bounce_launches += 1;
+            break;
+        }
         timer.begin(0);
         pool_rounds = chunk_rounds(bound);
         launch_bounce(g_stream, bound, pool_rounds, s->dev, b, current, next, s->results, s->list, info, s->block_counts,
@@ -354,11 +368,12 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
     if (rc != PTK_OK) return rc;
     HIP_TRY(hipStreamSynchronize(g_stream));
     const uint64_t segments = s->h_rays[0], extensions = s->h_rays[1] + b.n_paths, continued = s->h_rays[3];
+    sum_vertices += s->h_rays[4]; // vertices k_tail shaded after its first round
     const uint64_t bounce_bytes = BOUNCE_BYTES_PER_PATH * b.n_paths + BOUNCE_BYTES_PER_VERTEX * sum_vertices +
                                   BOUNCE_BYTES_PER_CONTINUED * continued + BOUNCE_BYTES_PER_ENDED * (sum_vertices - continued);
     for (int c = 0; c < N_CLASSES; c++) st.class_vertices[c] += class_vertices[c];
 #ifdef PTK_STAMPS
-    std::fprintf(stderr, "wave-cycles/16: shade %llu, rays %llu; vertices %llu, rays %llu\n", s->h_rays[4], s->h_rays[5],
+    std::fprintf(stderr, "wave-cycles/16: shade %llu, rays %llu; vertices %llu, rays %llu\n", s->h_rays[6], s->h_rays[7],
                  (unsigned long long) sum_vertices, (unsigned long long) (segments + extensions));
 #endif
     if (s->dev.has_meshes) { // k_traverse: ray request in, result out, 128-byte nodes, 72-byte triangle vertices
@@ -445,6 +460,16 @@ int ptk_init(int device) {
     const char* prof = std::getenv("PTK_PROFILE");
     if (prof && prof[0] == '1') g_profiling = true;
     return PTK_OK;
+}
+
+int ptk_set_option(const char* name, int64_t value) {
+    if (name && std::strcmp(name, "tail_records") == 0) {
+        if (value < 0 || value > static_cast<int64_t>(TAIL_RECORDS))
+            return fail(PTK_ERR_INVALID, "ptk_set_option: tail_records must be between 0 and 131072");
+        g_tail_records = static_cast<uint32_t>(value);
+        return PTK_OK;
+    }
+    return fail(PTK_ERR_INVALID, std::string("ptk_set_option: unknown option ") + (name ? name : "(null)"));
 }
 
 int ptk_set_profiling(int enabled) {

@@ -45,13 +45,21 @@ def test_primary_hits_match_oracle(scene_dirs, ob, name):
     np.testing.assert_allclose(got[4][hit], want[4][hit], rtol=1e-9, atol=1e-11)
 
 
+# tail_records: with the default the small test frames are traced by k_tail alone (one lane follows one
+# path to its end); 0 sends every bounce through the class sort and k_bounce (and, with meshes, the
+# deferral, k_traverse and k_bounce_resume); 1500 switches from the one to the other part-way.
+@pytest.mark.parametrize("tail_records", [131072, 0, 1500])
 @pytest.mark.parametrize("name", SCENES)
-def test_samples_match_oracle(scene_dirs, ob, name):
+def test_samples_match_oracle(scene_dirs, ob, name, tail_records):
     hs = pt.load_scene_directory(scene_dirs[name])
     n = hs.settings.width * hs.settings.height
     job = pt.make_job(0, n, 6, 2, 12345)
     want = ob.OracleScene(hs).trace_samples(job)
-    got = pt.DeviceScene(hs).trace_samples(job)
+    pt.set_option("tail_records", tail_records)
+    try:
+        got = pt.DeviceScene(hs).trace_samples(job)
+    finally:
+        pt.set_option("tail_records", 131072)
     for w, g, what in zip(want, got, ("radiance", "position", "normal")):
         w2, g2 = w.reshape(-1, 3), g.reshape(-1, 3)
         frac = _close_fraction(g2, w2)
@@ -60,14 +68,23 @@ def test_samples_match_oracle(scene_dirs, ob, name):
     np.testing.assert_allclose(mean_g, mean_w, rtol=2e-3)
 
 
-def test_results_do_not_depend_on_batch_size(scene_dirs):
-    hs = pt.load_scene_directory(scene_dirs["example"])
+@pytest.mark.parametrize("name", ["example", "mesh_rough_glass", "cloud"])
+def test_results_do_not_depend_on_batch_size_or_knobs(scene_dirs, name):
+    hs = pt.load_scene_directory(scene_dirs[name])
     n = hs.settings.width * hs.settings.height
     job = pt.make_job(0, n, 4, 0, 7)
     whole = pt.DeviceScene(hs).trace_samples(job)
     pieces = pt.DeviceScene(hs, max_paths_in_flight=1000).trace_samples(job)
     for a, b in zip(whole, pieces):
         assert np.array_equal(a, b)
+    for tail_records in (0, 700):
+        pt.set_option("tail_records", tail_records)
+        try:
+            other = pt.DeviceScene(hs).trace_samples(job)
+        finally:
+            pt.set_option("tail_records", 131072)
+        for a, b in zip(whole, other):
+            assert np.array_equal(a, b)
 
 
 def test_pixel_subrange_equals_full_frame(scene_dirs):

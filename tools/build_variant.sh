@@ -5,7 +5,7 @@ set -e
 name=$1; shift
 cd "$(dirname "$0")/../pathtracing_amd/csrc"
 tmp=$(mktemp -d)
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -Idevice -I. $*"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -Idevice -I. $*"
 hipcc $F -c device/kernels.hip -o $tmp/kernels.o &
 hipcc $F -c ptk_api.hip -o $tmp/ptk_api.o &
 hipcc $F -c device/denoise.hip -o $tmp/denoise.o &
