@@ -44,6 +44,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--bvh-leaf-size", type=int, default=0, help="override the scene setting bvh_leaf_size (mesh workload)")
     return ap.parse_args()
 
 
@@ -51,6 +52,8 @@ def build_workload(args, directory):
     from pathtracing_amd import scenes
     settings = dict(WIDTH=args.width, HEIGHT=args.height, samples_per_pixel=args.spp_per_step * args.steps,
                     samples_per_iteration=args.spp_per_step)
+    if args.bvh_leaf_size > 0:
+        settings["bvh_leaf_size"] = args.bvh_leaf_size
     if args.workload == "example":
         scenes.cornell_example(directory, **settings)
         return "scenes/example Cornell box (12 analytic objects)"

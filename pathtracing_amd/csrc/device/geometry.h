@@ -102,23 +102,82 @@ struct TraversalStack {
 };
 
 // Closest triangle of one mesh.  Children are visited nearest first and skipped when their entry
-// distance is not below the best hit so far (Node::intersect, src/bvh.cpp:193-213); the slab test is
-// BoundingBox::intersect (:60-83) evaluated on the outward-rounded fp32 boxes.
+// distance is not below the best hit so far (Node::intersect, src/bvh.cpp:193-213).
+//
+// The slab test (BoundingBox::intersect, :60-83) only culls, so it runs in fp32 on the fp32 boxes with
+// its rounding errors turned into a wider interval: t = (b - o) * (1/d) in fp32 is off by at most
+// 2^-24 (|o| + |b|) |1/d| from rounding o and the difference, plus 3 * 2^-24 |t| from 1/d and the
+// product.  Each axis interval is widened by 2^-22 (|o| + bound_abs) |1/d| and the final interval by
+// a factor 1 -+ 2^-21; a box the exact test accepts is never rejected.  Triangles are tested exactly
+// (fp64, the reference's watertight test).  The nearest child stays in a register; only the others
+// go through the stack.
+// bound_abs: largest absolute coordinate of the mesh's bounds.
 // any_hit: return at the first triangle found below t_best (enough for a shadow ray against a mesh
 // that no connection can pass through).
+PTK_DEV void sort_pair(float& ta, int32_t& ca, float& tb, int32_t& cb) {
+    const bool swap = tb < ta;
+    const float t = swap ? tb : ta;
+    const int32_t c = swap ? cb : ca;
+    tb = swap ? ta : tb;
+    cb = swap ? ca : cb;
+    ta = t;
+    ca = c;
+}
+
 PTK_DEV void mesh_closest_hit(const DevScene& sc, int32_t bvh_root, int64_t first_tri, const V3& org, const V3& dir,
-                              const RayPrep& rp, double& t_best, int& prim_best, TraversalStack& st, bool any_hit = false) {
+                              const RayPrep& rp, double& t_best, int& prim_best, TraversalStack& st, float bound_abs,
+                              bool any_hit = false) {
     if (bvh_root < 0) return;
-    const double idx = 1.0 / dir.x, idy = 1.0 / dir.y, idz = 1.0 / dir.z;
+    const float ox = static_cast<float>(org.x), oy = static_cast<float>(org.y), oz = static_cast<float>(org.z);
+    const float idx = static_cast<float>(1.0 / dir.x), idy = static_cast<float>(1.0 / dir.y), idz = static_cast<float>(1.0 / dir.z);
+    const float widen = 0x1p-22f;
+    const float pad_x = widen * (fabsf(ox) + bound_abs) * fabsf(idx);
+    const float pad_y = widen * (fabsf(oy) + bound_abs) * fabsf(idy);
+    const float pad_z = widen * (fabsf(oz) + bound_abs) * fabsf(idz);
+    const float FAR = __builtin_inff();
     st.sp = 0;
-    st.push(bvh_root, 0.0f);
-    while (st.sp > 0) {
-        StackEntry e = st.pop();
-        if (static_cast<double>(e.tnear) >= t_best) continue;
-        if (e.node < 0) { // leaf
-            uint32_t code = static_cast<uint32_t>(~e.node);
-            int64_t first = first_tri + (code >> 3);
-            int count = static_cast<int>(code & 7u) + 1;
+    int32_t node = bvh_root;
+    for (;;) {
+        if (node >= 0) {
+            st.nodes_visited++;
+            const BvhNode4& n = sc.nodes[node];
+            float tn[4];
+            int32_t ch[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                float t0 = (n.lo_x[c] - ox) * idx, t1 = (n.hi_x[c] - ox) * idx;
+                float lo = fmaxf(0.0f, fminf(t0, t1) - pad_x), hi = fmaxf(t0, t1) + pad_x;
+                t0 = (n.lo_y[c] - oy) * idy;
+                t1 = (n.hi_y[c] - oy) * idy;
+                lo = fmaxf(lo, fminf(t0, t1) - pad_y);
+                hi = fminf(hi, fmaxf(t0, t1) + pad_y);
+                t0 = (n.lo_z[c] - oz) * idz;
+                t1 = (n.hi_z[c] - oz) * idz;
+                lo = fmaxf(lo, fminf(t0, t1) - pad_z);
+                hi = fminf(hi, fmaxf(t0, t1) + pad_z);
+                lo *= 1.0f - 0x1p-21f;
+                hi *= 1.0f + 0x1p-21f;
+                ch[c] = n.child[c];
+                const bool ok = ch[c] != BVH_EMPTY && hi >= lo && static_cast<double>(lo) < t_best;
+                tn[c] = ok ? lo : FAR;
+            }
+            sort_pair(tn[0], ch[0], tn[1], ch[1]);
+            sort_pair(tn[2], ch[2], tn[3], ch[3]);
+            sort_pair(tn[0], ch[0], tn[2], ch[2]);
+            sort_pair(tn[1], ch[1], tn[3], ch[3]);
+            sort_pair(tn[1], ch[1], tn[2], ch[2]);
+            if (tn[3] < FAR) st.push(ch[3], tn[3]);
+            if (tn[2] < FAR) st.push(ch[2], tn[2]);
+            if (tn[1] < FAR) st.push(ch[1], tn[1]);
+            if (tn[0] < FAR) {
+                node = ch[0];
+                continue;
+            }
+        }
+        else { // leaf
+            const uint32_t code = static_cast<uint32_t>(~node);
+            const int64_t first = first_tri + (code >> 3);
+            const int count = static_cast<int>(code & 7u) + 1;
             st.triangles_tested += count;
             for (int i = 0; i < count; i++) {
                 double d;
@@ -128,44 +187,24 @@ PTK_DEV void mesh_closest_hit(const DevScene& sc, int32_t bvh_root, int64_t firs
                 }
             }
             if (any_hit && prim_best >= 0) return;
-            continue;
         }
-        st.nodes_visited++;
-        const BvhNode4& n = sc.nodes[e.node];
-        float tn[4];
-        int32_t ch[4];
-        int hits = 0;
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            int32_t child = n.child[c];
-            double t0 = (static_cast<double>(n.lo_x[c]) - org.x) * idx, t1 = (static_cast<double>(n.hi_x[c]) - org.x) * idx;
-            double lo = fmax(0.0, fmin(t0, t1)), hi = fmax(t0, t1);
-            t0 = (static_cast<double>(n.lo_y[c]) - org.y) * idy;
-            t1 = (static_cast<double>(n.hi_y[c]) - org.y) * idy;
-            lo = fmax(lo, fmin(t0, t1));
-            hi = fmin(hi, fmax(t0, t1));
-            t0 = (static_cast<double>(n.lo_z[c]) - org.z) * idz;
-            t1 = (static_cast<double>(n.hi_z[c]) - org.z) * idz;
-            lo = fmax(lo, fmin(t0, t1));
-            hi = fmin(hi, fmax(t0, t1));
-            bool ok = child != BVH_EMPTY && hi > lo && lo < t_best;
-            if (ok) {
-                // fp32 entry distance rounded down, so the pop-time cull never drops a valid child
-                float f = static_cast<float>(lo);
-                if (static_cast<double>(f) > lo) f = __uint_as_float(__float_as_uint(f) - 1u); // f > lo >= 0: next float down
-                // insertion sort, farthest first
-                int j = hits++;
-                while (j > 0 && tn[j - 1] < f) {
-                    tn[j] = tn[j - 1];
-                    ch[j] = ch[j - 1];
-                    j--;
-                }
-                tn[j] = f;
-                ch[j] = child;
+        for (;;) { // next entry of the stack that can still hold something closer
+            if (st.sp == 0) return;
+            const StackEntry e = st.pop();
+            if (static_cast<double>(e.tnear) < t_best) {
+                node = e.node;
+                break;
             }
         }
-        for (int j = 0; j < hits; j++) st.push(ch[j], tn[j]);
     }
+}
+
+// largest absolute coordinate of a mesh's bounds (DevShape::f[0..5])
+PTK_DEV float mesh_bound_abs(const DevShape& o) {
+    double m = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) m = fmax(m, fabs(o.f[k]));
+    return static_cast<float>(m) * (1.0f + 0x1p-20f);
 }
 
 struct HitInfo {
@@ -285,7 +324,7 @@ PTK_DEV void test_shape(const DevScene& sc, const DevShape& o, int index, const 
         for (int k = 0; k < N; k++) {
             double tb = rays[k].limit;
             int pb = -1;
-            mesh_closest_hit(sc, o.bvh_root, o.first_tri, org, rays[k].dir, rays[k].rp, tb, pb, st);
+            mesh_closest_hit(sc, o.bvh_root, o.first_tri, org, rays[k].dir, rays[k].rp, tb, pb, st, mesh_bound_abs(o));
             accept_hit(rays[k], pb >= 0, tb, index, pb, o.cls);
         }
     }

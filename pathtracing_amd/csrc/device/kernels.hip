@@ -882,7 +882,9 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_WAVES) void 
             // A shadow ray (even slot) is blocked by any triangle of a mesh that lets no connection
             // through: the march ends in black whichever triangle it meets first.
             const bool any_hit = (q.slot & 1u) == 0 && shapes[o].f[6] != 0;
-            mesh_closest_hit(sc, shapes[o].bvh_root, shapes[o].first_tri, org, dir, rp, best.t, prim, st, any_hit);
+            DevShape shape;
+            load_shape(shapes + o, shape);
+            mesh_closest_hit(sc, shape.bvh_root, shape.first_tri, org, dir, rp, best.t, prim, st, mesh_bound_abs(shape), any_hit);
             if (prim >= 0) {
                 best.obj = o;
                 best.prim = prim;
