@@ -200,20 +200,11 @@ def main():
     # The dominant kernel, timed with HIP events on the library's stream over the profiled steps of this timed
     # region and named as rocprofv3 shows it: k_bounce (every path vertex: shading, shadow ray, extension ray; in
     # scenes with meshes its time includes the resume pass) or, in scenes with meshes, k_traverse.
-    hs = host_scene.desc
-    tris = "true" if hs.n_triangles > 0 else "false"
-
-    def big(i):
-        return i >= 0 and (hs.maps[i].width > 1 or hs.maps[i].height > 1)
-    uv = "true" if any(big(m) for k in range(hs.n_materials)
-                       for m in (hs.materials[k].albedo_map, hs.materials[k].emission_color_map, hs.materials[k].light_intensity_map,
-                                 hs.materials[k].roughness_map, hs.materials[k].transparency_map)) else "false"
-    defer = "true" if any(hs.objects[i].type == pt._ffi.PTK_OBJ_MESH for i in range(hs.n_objects)) else "false"
     if fam["k_traverse"][0] > fam["k_bounce"][0]:
         kernel = "ptk::k_traverse"
         d_ms, d_bytes, d_launches = fam["k_traverse"]
     else:
-        kernel = f"ptk::k_bounce<{tris}, {uv}, {defer}>"
+        kernel = scene.bounce_kernel()
         d_ms, d_bytes, d_launches = fam["k_bounce"]
     achieved = d_bytes / (d_ms * 1e-3) / 1e9 if d_ms > 0 else 0.0
     traffic = None

@@ -257,6 +257,9 @@ int ptk_render_host(PtkScene* scene, const PtkRenderJob* job, double* image, dou
                     uint64_t* counters);
 
 int ptk_get_stats(PtkScene* scene, PtkStats* stats);
+/* Name, as a profiler shows it, of the k_bounce instantiation this scene is traced with (the library compiles one per
+ * combination of scene features).  No counterpart in the reference; for benchmark reports. */
+const char* ptk_scene_bounce_kernel(PtkScene* scene);
 int ptk_reset_stats(PtkScene* scene);
 /* No counterpart in the reference (it prints two wall-clock spans, app/pathtracer.cpp:309-372):
  * when enabled, HIP events bracket every kernel family on the library's stream and the

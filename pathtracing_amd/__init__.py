@@ -281,6 +281,10 @@ class DeviceScene:
         _check_dev(device_lib().ptk_get_stats(self._handle, C.byref(s)))
         return s
 
+    def bounce_kernel(self):
+        """Profiler name of the k_bounce instantiation this scene uses."""
+        return device_lib().ptk_scene_bounce_kernel(self._handle).decode()
+
     def reset_stats(self):
         _check_dev(device_lib().ptk_reset_stats(self._handle))
 

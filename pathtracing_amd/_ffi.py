@@ -126,6 +126,7 @@ DEVICE_PROTOTYPES = {
     "ptk_render": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(PtkRenderJob)]),
     "ptk_render_host": (C.c_int, [C.c_void_p, C.POINTER(PtkRenderJob), dptr, dptr, dptr, u64ptr]),
     "ptk_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PtkStats)]),
+    "ptk_scene_bounce_kernel": (C.c_char_p, [C.c_void_p]),
     "ptk_reset_stats": (C.c_int, [C.c_void_p]),
     "ptk_set_profiling": (C.c_int, [C.c_int]),
     "ptk_set_option": (C.c_int, [C.c_char_p, C.c_int64]),

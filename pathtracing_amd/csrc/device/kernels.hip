@@ -653,7 +653,7 @@ PTK_DEV void vertex_rays(const PathVertex& v, bool alive, double scatter_distanc
 // own forked random-number stream), the head of the next loop iteration (app/pathtracer.cpp:53-67:
 // where does the new ray end), and the record of the continuing path.  Returns the class of the
 // next vertex, -1 when the path ended.
-template<bool TRIS, bool UV>
+template<bool TRIS, bool UV, bool PASS>
 PTK_DEV int finish_vertex(const DevScene& sc, const PathPool& out, const SampleResults& res, uint32_t dst, PathVertex& v, bool alive,
                           double scatter_distance, const HitInfo& shadow_hit, const HitInfo& extension_hit, TraversalStack& st,
                           uint32_t* stat) {
@@ -661,7 +661,7 @@ PTK_DEV int finish_vertex(const DevScene& sc, const PathPool& out, const SampleR
         Rng march_rng{v.sh_key, 0};
         stat[2]++;
         stat[0]++;
-        V3 visible = march_to_light<TRIS, UV>(sc, v.point, v.sh_dir, static_cast<int>(v.medium), v.light_index, v.sh_dist, march_rng, st,
+        V3 visible = march_to_light<TRIS, UV, PASS>(sc, v.point, v.sh_dir, static_cast<int>(v.medium), v.light_index, v.sh_dist, march_rng, st,
                                               stat[0], shadow_hit);
         v.color = v.color + v.sh_contrib * visible;
     }
@@ -701,15 +701,17 @@ PTK_DEV int finish_vertex(const DevScene& sc, const PathPool& out, const SampleR
 // TRIS: the scene has triangles or meshes; UV: some material reads a map larger than 1x1 (texture
 // coordinates are needed).  Scenes without them get kernels without that code and its registers.
 // DEFER: vertices with a ray that enters the bounds of a mesh are queued for k_traverse and
-// k_bounce_resume instead of being finished here.
+// k_bounce_resume instead of being finished here.  PASS (DEFER kernels; true elsewhere): some material
+// lets connections through; without one these kernels contain no hierarchy walk at all.
 // statistics: per block [STATISTICS_SLOTS][N_STATISTICS].
-template<bool TRIS, bool UV, bool DEFER>
+template<bool TRIS, bool UV, bool DEFER, bool PASS>
 __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_bounce(DevScene sc, BatchParams b, PathPool in, PathPool out,
                                                                                       SampleResults res, const uint32_t* list,
                                                                                       const BinInfo* info, uint32_t rounds,
                                                                                       uint32_t* block_counts, uint32_t count_stride,
                                                                                       unsigned long long* statistics, DeferQueues queues) {
-    __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1]; // DEFER: later segments of a visibility march still walk inline
+    // DEFER: only the later segments of a visibility march walk a hierarchy here, and only if PASS
+    __shared__ StackEntry lds_stack[TRIS && (!DEFER || PASS) ? LDS_STACK_DEPTH * BLOCK : 1];
     __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
     __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
     __shared__ uint32_t queue_counts[BLOCK / 64][2];
@@ -768,7 +770,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
                 scan_objects<TRIS, DEFER ? MESH_DEFER : MESH_INLINE, 2>(sc, v.point, rays, st);
                 deferred = DEFER && (rays[0].needs_mesh || rays[1].needs_mesh);
                 origin = v.point;
-                if (!deferred) new_cls = finish_vertex<TRIS, UV>(sc, out, res, dst, v, alive, scatter_distance, rays[0].hit, rays[1].hit, st, stat);
+                if (!deferred) new_cls = finish_vertex<TRIS, UV, PASS>(sc, out, res, dst, v, alive, scatter_distance, rays[0].hit, rays[1].hit, st, stat);
                 PTK_STAMP(1)
             }
             if (DEFER) { // queue the deferred vertices of this round and their rays: two atomics per block
@@ -852,7 +854,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
             RayState rays[2];
             vertex_rays<TRIS>(v, alive, scatter_distance, rays);
             scan_objects<TRIS, MESH_INLINE, 2>(sc, v.point, rays, st);
-            cls = finish_vertex<TRIS, UV>(sc, out, res, i, v, alive, scatter_distance, rays[0].hit, rays[1].hit, st, stat);
+            cls = finish_vertex<TRIS, UV, true>(sc, out, res, i, v, alive, scatter_distance, rays[0].hit, rays[1].hit, st, stat);
             __threadfence(); // the record written above is read back by the next round
         }
     }
@@ -902,13 +904,13 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_WAVES) void 
 // the same two rays), scans the objects other than meshes, takes the closer of that hit and the
 // triangle k_traverse found, and goes on as k_bounce does.  The class counts go to the chunk the
 // vertex came from, by atomics (they are spread over as many addresses as there are chunks).
-template<bool UV>
+template<bool UV, bool PASS>
 __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_bounce_resume(DevScene sc, BatchParams b, PathPool in,
                                                                                              PathPool out, SampleResults res,
                                                                                              uint32_t* block_counts, uint32_t count_stride,
                                                                                              unsigned long long* statistics,
                                                                                              DeferQueues queues) {
-    __shared__ StackEntry lds_stack[LDS_STACK_DEPTH * BLOCK];
+    __shared__ StackEntry lds_stack[PASS ? LDS_STACK_DEPTH * BLOCK : 1];
     __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
     TraversalStack st = make_stack(lds_stack);
     const uint32_t n = queues.counters[1];
@@ -935,7 +937,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
                 rays[k].hit.cls = shapes[found.obj].cls;
             }
         }
-        const int new_cls = finish_vertex<true, UV>(sc, out, res, e.dst, v, alive, scatter_distance, rays[0].hit, rays[1].hit, st, stat);
+        const int new_cls = finish_vertex<true, UV, PASS>(sc, out, res, e.dst, v, alive, scatter_distance, rays[0].hit, rays[1].hit, st, stat);
         if (new_cls >= 0) atomicAdd(block_counts + static_cast<size_t>(new_cls) * count_stride + e.chunk, 1u);
     }
     add_block_statistics(statistics, wave_sums, stat);
@@ -1104,21 +1106,27 @@ void launch_bounce(hipStream_t s, uint32_t bound, uint32_t rounds, const DevScen
                    const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info, uint32_t* block_counts,
                    uint32_t count_stride, unsigned long long* statistics, const DeferQueues& queues) {
     const dim3 grid(min(chunk_blocks(bound, rounds), static_cast<uint32_t>(STATISTICS_SLOTS))), block(BLOCK);
-#define PTK_LAUNCH_BOUNCE(T, U, D)                                                                                                  \
-    hipLaunchKernelGGL((k_bounce<T, U, D>), grid, block, 0, s, sc, b, in, out, res, list, info, rounds, block_counts, count_stride, \
+#define PTK_LAUNCH_BOUNCE(T, U, D, P)                                                                                                  \
+    hipLaunchKernelGGL((k_bounce<T, U, D, P>), grid, block, 0, s, sc, b, in, out, res, list, info, rounds, block_counts, count_stride, \
                        statistics, queues)
     if (sc.has_meshes) {
         (void) hipMemsetAsync(queues.counters, 0, 2 * sizeof(uint32_t), s);
-        if (sc.needs_uv) PTK_LAUNCH_BOUNCE(true, true, true);
-        else PTK_LAUNCH_BOUNCE(true, false, true);
+        if (sc.needs_uv) {
+            if (sc.has_pass_through) PTK_LAUNCH_BOUNCE(true, true, true, true);
+            else PTK_LAUNCH_BOUNCE(true, true, true, false);
+        }
+        else {
+            if (sc.has_pass_through) PTK_LAUNCH_BOUNCE(true, false, true, true);
+            else PTK_LAUNCH_BOUNCE(true, false, true, false);
+        }
     }
     else if (sc.has_triangles) {
-        if (sc.needs_uv) PTK_LAUNCH_BOUNCE(true, true, false);
-        else PTK_LAUNCH_BOUNCE(true, false, false);
+        if (sc.needs_uv) PTK_LAUNCH_BOUNCE(true, true, false, true);
+        else PTK_LAUNCH_BOUNCE(true, false, false, true);
     }
     else {
-        if (sc.needs_uv) PTK_LAUNCH_BOUNCE(false, true, false);
-        else PTK_LAUNCH_BOUNCE(false, false, false);
+        if (sc.needs_uv) PTK_LAUNCH_BOUNCE(false, true, false, true);
+        else PTK_LAUNCH_BOUNCE(false, false, false, true);
     }
 #undef PTK_LAUNCH_BOUNCE
 }
@@ -1147,10 +1155,17 @@ void launch_bounce_resume(hipStream_t s, uint32_t bound, const DevScene& sc, con
                           const SampleResults& res, uint32_t* block_counts, uint32_t count_stride, unsigned long long* statistics,
                           const DeferQueues& queues) {
     const dim3 grid(min((bound + BLOCK - 1) / BLOCK + 1, static_cast<uint32_t>(STATISTICS_SLOTS))), block(BLOCK);
-    if (sc.needs_uv)
-        hipLaunchKernelGGL(k_bounce_resume<true>, grid, block, 0, s, sc, b, in, out, res, block_counts, count_stride, statistics, queues);
-    else
-        hipLaunchKernelGGL(k_bounce_resume<false>, grid, block, 0, s, sc, b, in, out, res, block_counts, count_stride, statistics, queues);
+#define PTK_LAUNCH_RESUME(U, P) \
+    hipLaunchKernelGGL((k_bounce_resume<U, P>), grid, block, 0, s, sc, b, in, out, res, block_counts, count_stride, statistics, queues)
+    if (sc.needs_uv) {
+        if (sc.has_pass_through) PTK_LAUNCH_RESUME(true, true);
+        else PTK_LAUNCH_RESUME(true, false);
+    }
+    else {
+        if (sc.has_pass_through) PTK_LAUNCH_RESUME(false, true);
+        else PTK_LAUNCH_RESUME(false, false);
+    }
+#undef PTK_LAUNCH_RESUME
 }
 
 void launch_sum_statistics(hipStream_t s, const unsigned long long* slots, unsigned long long* totals) {

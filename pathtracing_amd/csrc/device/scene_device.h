@@ -120,6 +120,7 @@ struct DevScene {
     int32_t n_lights, has_triangles; // has_triangles: any triangle or mesh object
     int32_t has_meshes;
     int32_t needs_uv; // some material reads a map larger than 1x1
+    int32_t has_pass_through, _pad1; // some material can let a connection to a light through (allow_direct_light)
     int32_t width, height;
     int32_t max_depth, min_depth, nee, aa;
     int32_t background_medium, background_is_black;

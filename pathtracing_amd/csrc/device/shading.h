@@ -347,7 +347,8 @@ PTK_DEV bool pick_light_point(const DevScene& sc, int shaded_object, const V3& f
 // transmittance of each segment's medium.  Returns emittance * transmittance, or black.
 // `h` holds the closest hit of the first segment (found by the caller, together with the
 // extension ray); later segments are traced here.
-template<bool TRIS, bool UV>
+// PASS = false: no material of the scene lets a connection through, so the march is its first segment.
+template<bool TRIS, bool UV, bool PASS>
 PTK_DEV V3 march_to_light(const DevScene& sc, V3 org, const V3& dir, int medium, int light_index, double distance_to_light,
                           Rng& rng, TraversalStack& st, uint32_t& rays, HitInfo h) {
     V3 transmittance = v3(1.0);
@@ -369,7 +370,7 @@ PTK_DEV V3 march_to_light(const DevScene& sc, V3 org, const V3& dir, int medium,
             if (fabs(distance_to_light - distance) > EPSILON) return v3(0.0);
             return emittance * transmittance;
         }
-        if (!allow_direct_light(sc, m, s, rng)) return v3(0.0);
+        if (!PASS || !allow_direct_light(sc, m, s, rng)) return v3(0.0);
         V3 normal = object_normal<TRIS>(sc, o, point, h.prim);
         bool outside = dot(dir, normal) < 0;
         org = point;

@@ -797,6 +797,13 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     }
     dev.has_meshes = 0;
     dev.needs_uv = 0;
+    dev.has_pass_through = 0;
+    for (const DevMaterial& m : materials) {
+        // Material::allow_direct_light (src/materials.cpp:55-60, :129-136)
+        auto ior = [&](int medium) { return medium >= 0 ? media[static_cast<size_t>(medium)].ior : 1.0; };
+        if (m.needs_uv || m.c_transparency > 0 || (m.type == PTK_MAT_TRANSPARENT && ior(m.internal_medium) == ior(m.external_medium)))
+            dev.has_pass_through = 1;
+    }
     for (const DevMaterial& m : materials)
         if (m.needs_uv) dev.needs_uv = 1;
     for (const DevObject& o : objects)
@@ -1034,6 +1041,16 @@ int ptk_render_host(PtkScene* s, const PtkRenderJob* job, double* image, double*
     HIP_TRY(hipMemcpy(normal + 3 * first, f->normal + 3 * first, n * 24, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(counters + first, f->counters + first, n * 8, hipMemcpyDeviceToHost));
     return PTK_OK;
+}
+
+const char* ptk_scene_bounce_kernel(PtkScene* s) {
+    static thread_local std::string name;
+    if (!s) return "";
+    const DevScene& d = s->dev;
+    auto tf = [](bool v) { return v ? "true" : "false"; };
+    name = std::string("ptk::k_bounce<") + tf(d.has_triangles) + ", " + tf(d.needs_uv) + ", " + tf(d.has_meshes) + ", " +
+           tf(!d.has_meshes || d.has_pass_through) + ">";
+    return name.c_str();
 }
 
 int ptk_get_stats(PtkScene* s, PtkStats* stats) {
