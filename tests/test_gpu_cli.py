@@ -39,6 +39,35 @@ def test_pathtracer_and_denoiser_write_the_reference_files(tmp_path):
     np.testing.assert_allclose(denoised, ob.oracle_denoise(tasks, image, position, normal), rtol=1e-10, atol=1e-13)
 
 
+def test_resume_continues_with_the_missing_samples(tmp_path):
+    work = tmp_path / "work"
+    (work / "temp").mkdir(parents=True)
+    exe = os.path.join(BIN, "pathtracer")
+    shape = (36, 48, 3)
+
+    def run(spp, *extra):
+        d = scenes.cornell_example(str(work / "scene"), WIDTH=48, HEIGHT=36, samples_per_pixel=spp, samples_per_iteration=4)
+        r = subprocess.run([exe, d, "--seed", "9", *extra], cwd=str(work), capture_output=True, text=True, timeout=300)
+        return r, np.fromfile(str(work / "temp" / "raw_pixel.dat")).reshape(shape)
+
+    r, whole = run(10)
+    assert r.returncode == 0, r.stderr
+    r, part = run(6)
+    assert r.returncode == 0, r.stderr
+    progress = np.fromfile(str(work / "temp" / "raw_progress.dat"), dtype=np.uint8)
+    assert bytes(progress[:8]) == b"PTKPROG1" and progress.size == 32 + 8 * 48 * 36
+    assert (np.frombuffer(progress[32:].tobytes(), dtype=np.uint64) == 6).all()
+    r, resumed = run(10, "--resume", "1")
+    assert r.returncode == 0, r.stderr
+    # same 10 sample indices per pixel, folded into the running mean in other portions
+    np.testing.assert_allclose(resumed, whole, rtol=1e-12, atol=1e-15)
+    assert not np.allclose(part, whole)
+    counts = np.fromfile(str(work / "temp" / "raw_progress.dat"), dtype=np.uint64)[4:]
+    assert (counts == 10).all()
+    r, _ = run(10, "--resume", "1", "--seed", "10")
+    assert r.returncode != 0 and "another size or seed" in r.stderr
+
+
 def test_usage_and_error_messages(tmp_path):
     r = subprocess.run([os.path.join(BIN, "pathtracer")], capture_output=True, text=True)
     assert r.returncode != 0 and "Usage: pathtracer <scene_directory>" in r.stderr
