@@ -13,7 +13,8 @@ films are summed over RCCL once at the end of the timed region.
 Workloads (`--workload`):
   example   the reference's scenes/example Cornell box at 1920x1080 (benchmark configuration 2)
   mesh      Cornell walls + a generated 1,048,576-triangle OBJ mesh at 1920x1080
-  cloud     scattering-medium + coloured-glass scene at 1920x1080, with the denoise pass timed apart
+  cloud     scattering-medium + coloured-glass scene at 1920x1080
+  room      living-room stand-in (23 objects, textured OBJ meshes, file textures, sphere light) at 1920x1080
 """
 import argparse
 import json
@@ -35,7 +36,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="example", choices=["example", "mesh", "cloud"])
+    ap.add_argument("--workload", default="example", choices=["example", "mesh", "cloud", "room"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp-per-step", type=int, default=8)
@@ -60,6 +61,9 @@ def build_workload(args, directory):
     if args.workload == "mesh":
         n = scenes.mesh_box(directory, n_lon=args.mesh_lon, n_lat=args.mesh_lat, material="gold", smooth=True, **settings)
         return f"Cornell walls + generated {n}-triangle OBJ mesh (MetallicMicrofacet)"
+    if args.workload == "room":
+        scenes.living_room(directory, mesh_lon=256, mesh_lat=129, texture_size=1024, **settings)
+        return "living-room stand-in: 23 objects, 5 OBJ meshes (294,912 triangles), 1024^2 file textures, sphere light"
     scenes.cloud_box(directory, **settings)
     return "Cornell box + homogeneous scattering cloud + coloured glass"
 

@@ -10,6 +10,8 @@ by the benchmark configuration are generated here:
 * ``material_zoo``      every material / object / light / camera feature in one small box
 * ``mesh_box``          Cornell walls + a procedurally generated OBJ mesh (up to millions of triangles)
 * ``cloud_box``         the Cornell box with a scattering-medium volume and coloured glass
+* ``living_room``       stand-in for the reference's living-room scene: 23 objects, OBJ meshes with file
+                        textures, a textured floor and wall, a small sphere light
 """
 import json
 import os
@@ -361,4 +363,87 @@ def emissive_mesh_box(directory, **settings):
                                   _sphere("gold_ball", [0.5, 0.25, -1], 0.25, "gold_material"), lamp]
     scene = {"valuemaps": list(_BASE_MAPS), "media": list(_BASE_MEDIA), "materials": materials, "objects": objects,
              "background_medium": "air_medium", "background_color": [0.0, 0.0, 0.0], "camera": dict(_EXAMPLE_CAMERA)}
+    return write_scene_directory(directory, scene, default_settings(**settings))
+
+
+def living_room(directory, mesh_lon=128, mesh_lat=65, texture_size=512, seed=11, **settings):
+    """Stand-in for the reference's scenes/living_room, whose meshes and textures are not in its repository:
+    the same kind of content -- 23 top-level objects, several OBJ meshes placed with center/size/orientation,
+    file textures (value-noise albedo, checker roughness, an emission map), one small sphere light (radius 0.1)
+    and a non-black background -- generated from `seed`."""
+    os.makedirs(directory, exist_ok=True)
+    n = texture_size
+    write_map_file(os.path.join(directory, "maps", "floor_albedo.map"), 0.25 + 0.6 * value_noise(n, n, 3, seed=seed, cells=16))
+    write_map_file(os.path.join(directory, "maps", "floor_roughness.map"), checker(n // 2, n // 2, 24, 0.05, 0.35))
+    write_map_file(os.path.join(directory, "maps", "wall_albedo.map"), 0.5 + 0.4 * value_noise(n, n // 2, 3, seed=seed + 1, cells=6))
+    write_map_file(os.path.join(directory, "maps", "fabric_albedo.map"), 0.15 + 0.7 * value_noise(n // 2, n // 2, 3, seed=seed + 2, cells=32))
+    write_map_file(os.path.join(directory, "maps", "metal_roughness.map"), 0.08 + 0.3 * value_noise(n // 4, n // 4, 1, seed=seed + 3)[:, :, 0])
+    screen = np.zeros((n // 4, n // 2, 3))
+    screen[n // 16: n // 4 - n // 16, n // 16: n // 2 - n // 16] = value_noise(n // 2 - n // 8, n // 8, 3, seed=seed + 4, cells=4)
+    write_map_file(os.path.join(directory, "maps", "screen_emission.map"), screen)
+    maps = list(_BASE_MAPS) + [
+        _map_file("floor_albedo", "ValueMap3D", "maps/floor_albedo.map"),
+        _map_file("floor_roughness", "ValueMap1D", "maps/floor_roughness.map"),
+        _map_file("wall_albedo", "ValueMap3D", "maps/wall_albedo.map"),
+        _map_file("fabric_albedo", "ValueMap3D", "maps/fabric_albedo.map"),
+        _map_file("metal_roughness", "ValueMap1D", "maps/metal_roughness.map"),
+        _map_file("screen_emission", "ValueMap3D", "maps/screen_emission.map"),
+        _map3("warm", [0.9922, 0.9569, 0.8627]), _map1("lamp_strength", 400), _map1("screen_strength", 3),
+        _map1("wood_roughness", 0.3), _map3("grey", [0.55, 0.55, 0.55]),
+    ]
+    materials = list(_BASE_MATERIALS) + [
+        _material("floor_material", "Glossy", albedo_map="floor_albedo", surface_refractive_index=1.3,
+                  roughness_map="floor_roughness"),
+        _material("wallpaper_material", "Diffuse", albedo_map="wall_albedo"),
+        _material("fabric_material", "Diffuse", albedo_map="fabric_albedo"),
+        _material("brushed_metal_material", "MetallicMicrofacet", albedo_map="grey", surface_refractive_index=1.5,
+                  extinction_coefficient=3.2, roughness_map="metal_roughness"),
+        _material("wood_material", "Glossy", albedo_map="fabric_albedo", surface_refractive_index=1.4,
+                  roughness_map="wood_roughness"),
+        _material("clear_glass_material", "Transparent", internal_medium="glass_medium", external_medium="air_medium"),
+        _material("lamp_material", "Diffuse", albedo_map="white", emission_color_map="warm",
+                  light_intensity_map="lamp_strength", is_light_source=True),
+        _material("screen_material", "Diffuse", albedo_map="grey", emission_color_map="screen_emission",
+                  light_intensity_map="screen_strength", is_light_source=True),
+    ]
+    models = os.path.join(directory, "models")
+    write_bumpy_sphere_obj(os.path.join(models, "cushion.obj"), mesh_lon, mesh_lat, seed=seed, bump=0.05)
+    write_bumpy_sphere_obj(os.path.join(models, "vase.obj"), mesh_lon, mesh_lat, seed=seed + 1, bump=0.12, quads=False)
+    write_bumpy_sphere_obj(os.path.join(models, "ornament.obj"), mesh_lon // 2, mesh_lat // 2 + 1, seed=seed + 2, bump=0.2)
+
+    def mesh(name, file, material, center, size, orientation, smooth=True):
+        return {"name": name, "type": "Object", "subtype": "ObjectUnion",
+                "parameters": {"file": "models/" + file, "material": material, "enable_smooth_shading": smooth,
+                               "center": center, "size": size, "orientation": dict(zip("XYZ", orientation))}}
+
+    objects = [
+        _rect("floor", [0, 0, 0], [1, 0, 0], [0, 0, -1], 2.2, 4, "floor_material"),
+        _rect("front_wall", [0, 1, -2], [1, 0, 0], [0, 1, 0], 2.2, 2, "wallpaper_material"),
+        _rect("left_wall", [-1.1, 1, 0], [0, 0, -1], [0, 1, 0], 4, 2, "white_diffuse_material"),
+        _rect("right_wall", [1.1, 1, 0], [0, 0, 1], [0, 1, 0], 4, 2, "wallpaper_material"),
+        _rect("roof", [0, 2, 0], [1, 0, 0], [0, 0, 1], 2.2, 4, "white_diffuse_material"),
+        _rect("rug", [0, 0.001, -0.8], [1, 0, 0], [0, 0, -1], 1.4, 1.2, "fabric_material"),
+        _rect("table_top", [0.0, 0.35, -1.0], [1, 0, 0], [0, 0, -1], 0.8, 0.5, "wood_material"),
+        _rect("shelf", [-1.0, 0.9, -1.2], [0, 0, -1], [1, 0, 0], 0.9, 0.2, "wood_material"),
+        _rect("screen", [0.3, 1.1, -1.995], [1, 0, 0], [0, 1, 0], 0.9, 0.5, "screen_material"),
+        _rect("window_pane", [1.09, 1.1, -0.6], [0, 0, 1], [0, 1, 0], 0.8, 0.8, "clear_glass_material"),
+        mesh("cushion_a", "cushion.obj", "fabric_material", [-0.55, 0.18, -0.7], 0.3, (0, 20, 10)),
+        mesh("cushion_b", "cushion.obj", "fabric_material", [0.6, 0.15, -0.3], 0.25, (15, 70, 0)),
+        mesh("vase", "vase.obj", "clear_glass_material", [0.2, 0.52, -1.0], 0.16, (0, 0, 0)),
+        mesh("metal_vase", "vase.obj", "brushed_metal_material", [-0.25, 0.5, -1.1], 0.14, (0, 45, 5), smooth=False),
+        mesh("ornament", "ornament.obj", "gold_material", [-0.95, 1.02, -1.2], 0.1, (30, 0, 0)),
+        _sphere("glass_ball", [0.05, 0.42, -0.85], 0.06, "cyan_glass_material"),
+        _sphere("mirror_ball", [-0.7, 0.12, -0.1], 0.12, "mirror_material"),
+        _sphere("rough_glass_ball", [0.75, 0.1, -1.2], 0.1, "rough_glass_material"),
+        _sphere("blue_ball", [-0.9, 0.2, -1.6], 0.2, "blue_diffuse_material"),
+        _sphere("gold_ball", [0.85, 0.45, -1.7], 0.12, "gold_material"),
+        {"name": "table_leg", "type": "Object", "subtype": "Triangle",
+         "parameters": {"p1": [-0.1, 0.0, -1.0], "p2": [0.1, 0.0, -1.0], "p3": [0.0, 0.35, -1.0], "material": "wood_material"}},
+        _sphere("lamp", [-0.5, 1.7, -0.9], 0.1, "lamp_material"),
+        _sphere("lamp_shade", [-0.5, 1.7, -0.9], 0.2, "clear_glass_material"),
+    ]
+    assert len(objects) == 23
+    scene = {"valuemaps": maps, "media": list(_BASE_MEDIA), "materials": materials, "objects": objects,
+             "background_medium": "air_medium", "background_color": [0.02, 0.03, 0.05],
+             "camera": _camera([0, 0.9, 1.9], 88, 2, 0, 0.036, 0.036)}
     return write_scene_directory(directory, scene, default_settings(**settings))

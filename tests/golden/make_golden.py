@@ -42,6 +42,7 @@ SCENES = {
     "cloud": ("cloud_box", dict(WIDTH=48, HEIGHT=32), 3),
     "fog": ("cloud_box", dict(fog=True, WIDTH=48, HEIGHT=32), 3),
     "lamp": ("emissive_mesh_box", dict(WIDTH=48, HEIGHT=32), 3),
+    "room": ("living_room", dict(mesh_lon=24, mesh_lat=13, texture_size=64, WIDTH=48, HEIGHT=32), 3),
 }
 SEEDS = (101, 202, 303)
 
@@ -53,8 +54,10 @@ def build_scene(name, directory):
 
 
 def main():
+    """Without arguments regenerates everything; with scene names, only their primary_/samples_ files."""
     tmp = tempfile.mkdtemp(prefix="ptk_golden_")
-    for name in SCENES:
+    only = sys.argv[1:]
+    for name in (only or SCENES):
         d = os.path.join(tmp, name)
         spp = build_scene(name, d)
         hs = pt.load_scene_directory(d, enable_anti_aliasing=0)
@@ -71,6 +74,8 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"samples_{name}.npz"), seeds=np.array(SEEDS), spp=spp, color=color,
                             position=pos, normal=nrm)
         print(name, "ok", color.mean())
+    if only:
+        return
 
     # denoise: input triple from a seeded reference render
     d = os.path.join(tmp, "denoise")

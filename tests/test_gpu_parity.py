@@ -11,7 +11,7 @@ import pathtracing_amd as pt
 pytestmark = pytest.mark.gpu
 
 SCENES = ["example", "zoo", "zoo_circle", "zoo_square", "mesh_gold", "mesh_rough_glass", "mesh_glass",
-          "mesh_textured", "cloud", "fog", "lamp"]
+          "mesh_textured", "cloud", "fog", "lamp", "room"]
 
 
 @pytest.fixture(scope="module")
