@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--denoise", action="store_true", help="also time the shipped denoising pipeline on the device film")
+    ap.add_argument("--tail-records", type=int, default=-1, help="override the library's tail_records knob")
     ap.add_argument("--bvh-leaf-size", type=int, default=0, help="override the scene setting bvh_leaf_size (mesh workload)")
     return ap.parse_args()
 
@@ -66,6 +68,11 @@ def build_workload(args, directory):
         return "living-room stand-in: 23 objects, 5 OBJ meshes (294,912 triangles), 1024^2 file textures, sphere light"
     scenes.cloud_box(directory, **settings)
     return "Cornell box + homogeneous scattering cloud + coloured glass"
+
+
+def scenes_default_pipeline():
+    from pathtracing_amd import scenes
+    return [dict(mode=t["mode"], **t["parameters"]) for t in scenes.DEFAULT_DENOISING["pipeline"]]
 
 
 def cpu_baseline(host_scene, args, threads):
@@ -112,6 +119,8 @@ def main():
     import pathtracing_amd as pt
 
     pt.init(local_rank)
+    if args.tail_records >= 0:
+        pt.set_option("tail_records", args.tail_records)
     tmp = tempfile.mkdtemp(prefix=f"ptk_bench_r{rank}_")
     workload_name = build_workload(args, tmp)
     t_build = time.perf_counter()
@@ -246,6 +255,21 @@ def main():
                  "triangles_per_traversed_ray": st.triangles_tested / max(st.traversed_rays, 1)},
         "roofline": roofline,
     }
+    if args.denoise and not distributed:
+        # the reference's shipped pipeline (denoising.json: median 3x3 threshold 0.5, then 4 a-trous iterations) on the
+        # rendered film, device to device; bytes: 48 B/pixel for the median, 96 B/pixel per a-trous iteration
+        tasks = pt.make_denoise_tasks(scenes_default_pipeline())
+        scratch = pt.Film(W, H)
+        pt.denoise_film(tasks, film, scratch)
+        pt.sync()
+        reps = 10
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            pt.denoise_film(tasks, film, scratch)
+        pt.sync()
+        dt = (time.perf_counter() - t1) / reps
+        out["denoise"] = {"pipeline": "median 3x3 + a-trous x4 (the reference's denoising.json)", "ms_per_frame": dt * 1e3,
+                          "Mpixels_per_s": n_pixels / dt / 1e6, "algorithmic_GBps": n_pixels * (48 + 4 * 96) / dt / 1e9}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         threads = args.cpu_threads or min(16, os.cpu_count() or 1)
         out["cpu_baseline"] = cpu_baseline(host_scene, args, threads)

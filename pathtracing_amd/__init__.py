@@ -300,6 +300,15 @@ class DeviceScene:
             pass
 
 
+def denoise_film(tasks, film, scratch_film):
+    """Applies a denoising pipeline to the image of a device-resident film, in place and asynchronously on the
+    library's stream; `scratch_film` (same size) lends its image buffer as scratch space."""
+    img, pos, nrm, _ = film.device_pointers()
+    scratch = scratch_film.device_pointers()[0]
+    arr = (PtkDenoiseTask * len(tasks))(*tasks)
+    _check_dev(device_lib().ptk_denoise_device(arr, len(tasks), film.width, film.height, img, pos, nrm, scratch))
+
+
 def denoise(tasks, image, position, normal):
     """Applies a denoising pipeline on the GPU; returns the filtered copy of `image`."""
     init(_dev_initialised if _dev_initialised is not None else 0)

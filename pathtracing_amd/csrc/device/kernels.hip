@@ -37,6 +37,9 @@ constexpr int BLOCK = 256;
 #ifndef PTK_BOUNCE_WAVES
 #define PTK_BOUNCE_WAVES 2
 #endif
+#ifndef PTK_BOUNCE_UV_WAVES
+#define PTK_BOUNCE_UV_WAVES 2
+#endif
 #ifndef PTK_TRAVERSE_WAVES
 #define PTK_TRAVERSE_WAVES 6
 #endif
@@ -705,7 +708,7 @@ PTK_DEV int finish_vertex(const DevScene& sc, const PathPool& out, const SampleR
 // lets connections through; without one these kernels contain no hierarchy walk at all.
 // statistics: per block [STATISTICS_SLOTS][N_STATISTICS].
 template<bool TRIS, bool UV, bool DEFER, bool PASS>
-__global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_bounce(DevScene sc, BatchParams b, PathPool in, PathPool out,
+__global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES : PTK_BOUNCE_WAVES) void k_bounce(DevScene sc, BatchParams b, PathPool in, PathPool out,
                                                                                       SampleResults res, const uint32_t* list,
                                                                                       const BinInfo* info, uint32_t rounds,
                                                                                       uint32_t* block_counts, uint32_t count_stride,
@@ -831,7 +834,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_
 // bounce.  Same per-vertex code as k_bounce, hence the same results.  Round 0 reads record list[i] of
 // `in` and writes record i of `out`; later rounds update record i of `out` in place.
 template<bool TRIS, bool UV>
-__global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_tail(DevScene sc, BatchParams b, PathPool in, PathPool out,
+__global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES : PTK_BOUNCE_WAVES) void k_tail(DevScene sc, BatchParams b, PathPool in, PathPool out,
                                                                                     SampleResults res, const uint32_t* list,
                                                                                     const BinInfo* info, unsigned long long* statistics) {
     __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1];
@@ -905,7 +908,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_WAVES) void 
 // triangle k_traverse found, and goes on as k_bounce does.  The class counts go to the chunk the
 // vertex came from, by atomics (they are spread over as many addresses as there are chunks).
 template<bool UV, bool PASS>
-__global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_BOUNCE_WAVES) void k_bounce_resume(DevScene sc, BatchParams b, PathPool in,
+__global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES : PTK_BOUNCE_WAVES) void k_bounce_resume(DevScene sc, BatchParams b, PathPool in,
                                                                                              PathPool out, SampleResults res,
                                                                                              uint32_t* block_counts, uint32_t count_stride,
                                                                                              unsigned long long* statistics,
