@@ -167,3 +167,59 @@ def test_statistics_count_paths_and_rays(scene_dirs, ob):
     # the reference marches them before discarding them
     assert 0.85 * o.shadow_rays <= s.shadow_rays <= o.shadow_rays
     assert s.algorithmic_bytes > 0
+
+
+@pytest.mark.parametrize("overrides", [
+    dict(enable_next_event_estimation=0),
+    dict(enable_anti_aliasing=0),
+    dict(max_recursion_depth=0),
+    dict(max_recursion_depth=1, min_recursion_steps=0),
+    dict(min_recursion_steps=0),
+    dict(min_recursion_steps=50, max_recursion_depth=12),
+], ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
+@pytest.mark.parametrize("name", ["example", "zoo", "mesh_rough_glass", "fog"])
+def test_settings_variations_match_oracle(scene_dirs, ob, name, overrides):
+    hs = pt.load_scene_directory(scene_dirs[name], **overrides)
+    n = hs.settings.width * hs.settings.height
+    job = pt.make_job(0, n, 3, 1, 4242)
+    want = ob.OracleScene(hs).trace_samples(job)
+    for tail_records in (131072, 0):
+        pt.set_option("tail_records", tail_records)
+        try:
+            got = pt.DeviceScene(hs).trace_samples(job)
+        finally:
+            pt.set_option("tail_records", 131072)
+        for w, g, what in zip(want, got, ("radiance", "position", "normal")):
+            frac = _close_fraction(g.reshape(-1, 3), w.reshape(-1, 3))
+            assert frac >= 0.999, f"{name} {overrides} {what}: only {frac:.5f} of the samples agree"
+
+
+def test_degenerate_jobs_and_scenes(tmp_path, ob):
+    from pathtracing_amd import scenes
+    # a scene with no light and one with nothing but the background
+    scene = scenes.cornell_example_dict()
+    scene["objects"] = [o for o in scene["objects"] if o["name"] != "light_source"]
+    dark = scenes.write_scene_directory(str(tmp_path / "dark"), scene, scenes.default_settings(WIDTH=32, HEIGHT=24))
+    scene = scenes.cornell_example_dict()
+    scene["objects"] = []
+    scene["background_color"] = [0.25, 0.5, 0.75]
+    empty = scenes.write_scene_directory(str(tmp_path / "empty"), scene, scenes.default_settings(WIDTH=32, HEIGHT=24))
+    for d in (dark, empty):
+        hs = pt.load_scene_directory(d)
+        n = hs.settings.width * hs.settings.height
+        job = pt.make_job(0, n, 2, 0, 1)
+        got, want = pt.DeviceScene(hs).trace_samples(job), ob.OracleScene(hs).trace_samples(job)
+        for g, w in zip(got, want):
+            np.testing.assert_allclose(g, w, rtol=1e-9, atol=1e-12)
+    assert np.allclose(got[0], [0.25, 0.5, 0.75])
+    # jobs of zero pixels or zero samples change nothing; a one-pixel job works
+    hs = pt.load_scene_directory(dark)
+    dev, film = pt.DeviceScene(hs), pt.Film(32, 24)
+    dev.render(film, pt.make_job(5, 1, 3, 0, 1))
+    dev.render(film, pt.make_job(0, 0, 3, 0, 1))
+    dev.render(film, pt.make_job(0, 32 * 24, 0, 0, 1))
+    counters = film.download()[3]
+    assert counters.sum() == 3 and counters.reshape(-1)[5] == 3
+    # out-of-range jobs are refused, not clamped
+    with pytest.raises(pt.PtkError):
+        dev.render(film, pt.make_job(32 * 24 - 1, 2, 1, 0, 1))
