@@ -112,3 +112,29 @@ def test_counter_streams_converge_to_the_reference_image(built):
         mae = np.mean(np.abs(image[..., c] - ref[..., c])) / np.mean(ref[..., c])
         assert mae < 0.2, (c, mae)
         assert abs(image[..., c].mean() - ref[..., c].mean()) / ref[..., c].mean() < 0.06
+
+
+VARIATIONS = [
+    dict(enable_next_event_estimation=0),
+    dict(max_recursion_depth=0),
+    dict(max_recursion_depth=1, min_recursion_steps=0),
+    dict(min_recursion_steps=0),
+    dict(min_recursion_steps=50, max_recursion_depth=12),
+    dict(enable_anti_aliasing=0),
+]
+
+
+@pytest.mark.skipif(not ob.ref_available(), reason="the reference is built from /root/reference (build container only)")
+@pytest.mark.parametrize("overrides", VARIATIONS, ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
+@pytest.mark.parametrize("name", ["example", "zoo", "mesh_rough_glass", "fog", "room"])
+def test_settings_variations_bit_exact_against_the_live_reference(built, name, overrides):
+    """Settings the fixtures do not cover, checked against the reference itself where it can be built."""
+    hs = pt.load_scene_directory(built[name], **overrides)
+    n = hs.settings.width * hs.settings.height
+    job = pt.make_job(0, n, 2, 0, 0)
+    ref = ob.RefScene(hs)
+    ref.seed(11, 22, 33)
+    want = ref.trace_samples(job)
+    got = ob.OracleScene(hs).trace_samples(job, ob.stream_rng(11, 22, 33))
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g, equal_nan=True)
