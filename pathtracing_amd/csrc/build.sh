@@ -11,12 +11,15 @@ g++ -std=c++17 -O2 -Wall -Wextra -fPIC -shared -I../../include host/host_loader.
 # same ones as the CPU build of the reference (x86-64 without FMA contraction); costs about 4 % on the Cornell scene.
 HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -Idevice -I. ${PTK_HIPFLAGS}"
 mkdir -p build
-hipcc $HIPFLAGS -c device/kernels.hip -o build/kernels.o &
-hipcc $HIPFLAGS -c device/denoise.hip -o build/denoise.o &
-hipcc $HIPFLAGS -c ptk_api.hip -o build/ptk_api.o &
+# The instantiations of the path-tracing kernel templates are spread over device/variants/*.hip so that they
+# compile side by side (PTK_JOBS at a time).
+SOURCES="device/kernels.hip device/denoise.hip ptk_api.hip $(ls device/variants/*.hip)"
+OBJECTS=""
+for src in $SOURCES; do OBJECTS="$OBJECTS build/$(basename $src .hip).o"; done
 g++ -std=c++17 -O3 -fPIC -I../../include -I. -c host/bvh_builder.cpp -o build/bvh_builder.o &
+printf '%s\n' $SOURCES | xargs -P "${PTK_JOBS:-8}" -I{} sh -c "hipcc $HIPFLAGS -c {} -o build/\$(basename {} .hip).o"
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC build/kernels.o build/denoise.o build/ptk_api.o build/bvh_builder.o -o $OUT/libptk.so -lpthread
+hipcc --offload-arch=gfx950 -shared -fPIC $OBJECTS build/bvh_builder.o -o $OUT/libptk.so -lpthread
 mkdir -p $OUT/bin
 for app in pathtracer denoiser; do
   g++ -std=c++17 -O2 -Wall -Wextra -I../../include app/${app}_main.cpp -o $OUT/bin/$app -L$OUT -lptk -lptkhost \

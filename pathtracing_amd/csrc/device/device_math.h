@@ -26,11 +26,16 @@ PTK_DEV V3 operator*(const V3& a, const V3& b) { return V3{a.x * b.x, a.y * b.y,
 PTK_DEV V3 operator*(const V3& a, double s) { return V3{a.x * s, a.y * s, a.z * s}; }
 PTK_DEV V3 operator*(double s, const V3& a) { return V3{a.x * s, a.y * s, a.z * s}; }
 PTK_DEV V3 operator/(const V3& a, double s) { return V3{a.x / s, a.y / s, a.z / s}; }
-PTK_DEV double dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// The library is built without automatic contraction (every kernel variant must round the same way), so
+// fused multiply-adds are written out where they are wanted: sums of products cost 3 instructions instead
+// of 5 and lose one rounding fewer than the reference's x86-64 build.
+PTK_DEV double dot(const V3& a, const V3& b) { return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)); }
 PTK_DEV V3 cross(const V3& a, const V3& b) {
-    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+    return V3{fma(a.y, b.z, -(a.z * b.y)), fma(a.z, b.x, -(a.x * b.z)), fma(a.x, b.y, -(a.y * b.x))};
 }
-PTK_DEV double len2(const V3& a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+PTK_DEV double len2(const V3& a) { return dot(a, a); }
+// a + b * s
+PTK_DEV V3 mad(const V3& b, double s, const V3& a) { return V3{fma(b.x, s, a.x), fma(b.y, s, a.y), fma(b.z, s, a.z)}; }
 PTK_DEV double len(const V3& a) { return sqrt(len2(a)); }
 PTK_DEV V3 normalize(const V3& a) { return a / len(a); }
 PTK_DEV double vmax(const V3& a) { return fmax(fmax(a.x, a.y), a.z); }
@@ -98,7 +103,7 @@ PTK_DEV bool solve_quadratic(double b, double c, double& distance) { // :52-71
 // solve_quadratic without branches, so that the tests of two rays interleave: the square root of a
 // negative discriminant is a NaN, which fails every comparison that follows.
 PTK_DEV bool solve_quadratic_select(double b, double c, double& distance) {
-    double discriminant = b * b - 4.0 * c;
+    double discriminant = fma(b, b, -4.0 * c);
     double root = sqrt(discriminant);
     double minimum_solution = -0.5 * (b + root), maximum_solution = -0.5 * (b - root);
     bool minimum_ok = minimum_solution > EPSILON, maximum_ok = maximum_solution > EPSILON;
@@ -130,11 +135,11 @@ PTK_DEV V3 sample_cosine_hemisphere(const V3& normal, Rng& rng) { // :115-126
     double x = c * radius;
     double y = s * radius;
     double z = sqrt(1 - x * x - y * y);
-    return x_hat * x + y_hat * y + normal * z;
+    return mad(x_hat, x, mad(y_hat, y, normal * z));
 }
 
 PTK_DEV V3 reflect_vector(const V3& direction, const V3& normal) { // :128-130
-    return direction - normal * 2.0 * dot(normal, direction);
+    return mad(normal, -2.0 * dot(normal, direction), direction);
 }
 
 PTK_DEV V3 refract_vector(const V3& incident, const V3& normal, double eta) { // :132-141

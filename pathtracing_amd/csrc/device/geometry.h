@@ -234,8 +234,11 @@ struct RayState {
     V3 dir;
     double dir_dot_org;
     RayPrep rp;
+    // A hit at distance d is taken when d < limit: the distance of the closest hit so far, and before any
+    // hit the smallest double above the ray's t_max (the reference takes d <= t_max for the first hit and
+    // d < closest afterwards).
     double limit;
-    HitInfo hit;
+    int obj, prim;   // closest hit so far: object (-1: none) and triangle (leaf order; 0 for other shapes)
     bool needs_mesh; // MESH_DEFER: the ray enters the bounds of some mesh before its limit
 };
 // What the object scan does with a mesh: walk its hierarchy, only test its bounds (and leave the
@@ -258,14 +261,20 @@ PTK_DEV double box_entry(const double* bounds, const V3& org, const V3& dir) {
     return hi >= lo ? lo : INF;
 }
 
-PTK_DEV void accept_hit(RayState& r, bool success, double d, int index, int prim, int cls) {
-    if (success && d > EPSILON && d < r.hit.t) {
-        r.hit.t = d;
-        r.hit.obj = index;
-        r.hit.prim = prim;
-        r.hit.cls = cls;
+PTK_DEV void accept_hit(RayState& r, bool success, double d, int index, int prim) {
+    if (success && d > EPSILON && d < r.limit) {
         r.limit = d;
+        r.obj = index;
+        r.prim = prim;
     }
+}
+
+// smallest double above t (t itself when it is infinite)
+PTK_DEV double next_above(double t) {
+    if (!(fabs(t) < INF)) return t;
+    long long bits = __double_as_longlong(t);
+    if (t == 0) return 0x1p-1074;
+    return __longlong_as_double(t > 0 ? bits + 1 : bits - 1);
 }
 
 template<bool TRIS, int MODE, int N>
@@ -277,8 +286,8 @@ PTK_DEV void test_shape(const DevScene& sc, const DevShape& o, int index, const 
         for (int k = 0; k < N; k++) {
             double d;
             double b = 2 * (rays[k].dir_dot_org - dot(rays[k].dir, c));
-            bool success = solve_quadratic_select(b, cc, d) && !(d > rays[k].limit);
-            accept_hit(rays[k], success, d, index, 0, o.cls);
+            bool success = solve_quadratic_select(b, cc, d);
+            accept_hit(rays[k], success, d, index, 0);
         }
     }
     else if (o.type == PTK_OBJ_PLANE || o.type == PTK_OBJ_RECTANGLE) { // :185-211, :237-255
@@ -291,7 +300,7 @@ PTK_DEV void test_shape(const DevScene& sc, const DevShape& o, int index, const 
         for (int k = 0; k < N; k++) {
             double ddn = -dot(rays[k].dir, nrm);
             d[k] = shifted_dot_n / ddn;
-            success[k] = !(fabs(ddn) < EPSILON) && !(d[k] < EPSILON) && !(d[k] > rays[k].limit);
+            success[k] = !(fabs(ddn) < EPSILON); // d >= EPSILON and d <= t_max are implied by accept_hit's tests
         }
         if (o.type == PTK_OBJ_RECTANGLE) {
             V3 a1 = v3(o.f[6], o.f[7], o.f[8]), a2 = v3(o.f[9], o.f[10], o.f[11]);
@@ -299,19 +308,19 @@ PTK_DEV void test_shape(const DevScene& sc, const DevShape& o, int index, const 
             double half1 = o.f[12] / 2.0 + EPSILON, half2 = o.f[13] / 2.0 + EPSILON;
 #pragma unroll
             for (int k = 0; k < N; k++) {
-                bool outside = fabs(s1 + dot(rays[k].dir, a1) * d[k]) > half1 || fabs(s2 + dot(rays[k].dir, a2) * d[k]) > half2;
+                bool outside = fabs(fma(dot(rays[k].dir, a1), d[k], s1)) > half1 || fabs(fma(dot(rays[k].dir, a2), d[k], s2)) > half2;
                 success[k] = success[k] && !outside;
             }
         }
 #pragma unroll
-        for (int k = 0; k < N; k++) accept_hit(rays[k], success[k], d[k], index, 0, o.cls);
+        for (int k = 0; k < N; k++) accept_hit(rays[k], success[k], d[k], index, 0);
     }
     else if (TRIS && o.type == PTK_OBJ_TRIANGLE) {
 #pragma unroll
         for (int k = 0; k < N; k++) {
             double d = INF;
             bool success = triangle_hit(sc.tri_hot[o.first_tri], org, rays[k].rp, rays[k].limit, d);
-            accept_hit(rays[k], success, d, index, o.first_tri, o.cls);
+            accept_hit(rays[k], success, d, index, o.first_tri);
         }
     }
     else if (TRIS && MODE == MESH_DEFER) { // mesh: bounds only
@@ -325,7 +334,7 @@ PTK_DEV void test_shape(const DevScene& sc, const DevShape& o, int index, const 
             double tb = rays[k].limit;
             int pb = -1;
             mesh_closest_hit(sc, o.bvh_root, o.first_tri, org, rays[k].dir, rays[k].rp, tb, pb, st, mesh_bound_abs(o));
-            accept_hit(rays[k], pb >= 0, tb, index, pb, o.cls);
+            accept_hit(rays[k], pb >= 0, tb, index, pb);
         }
     }
 }
@@ -370,17 +379,31 @@ PTK_DEV RayState ray_state(const V3& org, const V3& dir, double t_max) {
     r.dir_dot_org = dot(dir, org);
     r.rp = RayPrep{};
     if (TRIS) r.rp = prepare_ray(dir);
-    r.limit = t_max; // ray.t_max
-    no_hit(r.hit);
+    r.limit = next_above(t_max);
+    r.obj = -1;
+    r.prim = 0;
     r.needs_mesh = false;
     return r;
+}
+
+// The closest hit a finished scan left in the ray's state.
+PTK_DEV HitInfo hit_of(const DevScene& sc, const RayState& r) {
+    HitInfo h;
+    no_hit(h);
+    if (r.obj >= 0) {
+        h.t = r.limit;
+        h.obj = r.obj;
+        h.prim = r.prim;
+        h.cls = sc.objects[r.obj].mat.type; // the class of a surface vertex is its material type
+    }
+    return h;
 }
 
 template<bool TRIS>
 PTK_DEV bool closest_hit(const DevScene& sc, const V3& org, const V3& dir, double t_max, HitInfo& hit, TraversalStack& st) {
     RayState rays[1] = {ray_state<TRIS>(org, dir, t_max)};
     scan_objects<TRIS, MESH_INLINE, 1>(sc, org, rays, st);
-    hit = rays[0].hit;
+    hit = hit_of(sc, rays[0]);
     return hit.obj >= 0;
 }
 

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <string>
+
 #include "scene_device.h"
 
 namespace ptk {
@@ -30,6 +32,11 @@ void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_
 void launch_bounce(hipStream_t s, uint32_t bound, uint32_t rounds, const DevScene& sc, const BatchParams& b, const PathPool& in,
                    const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info, uint32_t* block_counts,
                    uint32_t count_stride, unsigned long long* statistics, const DeferQueues& queues);
+// Name (as the profiler prints it) of the k_bounce instantiation launch_bounce uses for this scene.
+std::string bounce_kernel_name(const DevScene& sc);
+// false: every scene runs the general kernels (all features compiled in, tables read from memory) instead of the
+// ones specialised on its contents; the results are the same.
+void set_specialised_kernels(bool on);
 // Every remaining bounce of the paths in `list` (at most `bound` of them, bound <= TAIL_RECORDS) in one launch.
 constexpr uint32_t TAIL_RECORDS = 131072;
 void launch_tail(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,

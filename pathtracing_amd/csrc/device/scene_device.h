@@ -65,7 +65,10 @@ struct DevObject {
     double mesh_light_area;  // mesh light: last cumulative area
     int32_t index, _pad2;    // position in the scene's object table
     DevMaterial mat;         // copy of materials[material]: one load reaches everything shading needs
+    double _pad3;            // 328 bytes: consecutive objects start 18 LDS banks apart, so lanes that read one
+                             // field of different objects (8-byte reads) do not collide on a bank
 };
+static_assert(sizeof(DevObject) == 328, "the LDS copies of the object table rely on this stride");
 
 // What the closest-hit loop reads per object: 128 bytes fetched by two scalar loads.
 //   sphere            f[0..2] centre, f[3] radius
@@ -120,7 +123,8 @@ struct DevScene {
     int32_t n_lights, has_triangles; // has_triangles: any triangle or mesh object
     int32_t has_meshes;
     int32_t needs_uv; // some material reads a map larger than 1x1
-    int32_t has_pass_through, _pad1; // some material can let a connection to a light through (allow_direct_light)
+    int32_t has_pass_through;    // some material can let a connection to a light through (allow_direct_light)
+    int32_t tables_fit_lds;      // objects + light_objects + media take at most LDS_SCENE_DOUBLES doubles
     int32_t width, height;
     int32_t max_depth, min_depth, nee, aa;
     int32_t background_medium, background_is_black;
@@ -141,6 +145,9 @@ struct DevScene {
     const int32_t* light_tri_index;      // per mesh light: root-sorted position -> triangle (leaf order)
     uint32_t class_mask;                 // material classes present in the scene (+ scatter bit)
 };
+
+// LDS every block of the shading kernels sets aside for copies of the object, light and medium tables
+constexpr int LDS_SCENE_DOUBLES = 4096;
 
 constexpr int N_STATISTICS = 8;         // values per statistics slot (see kernels.hip)
 constexpr int STATISTICS_SLOTS = 8192; // per-block slots = the largest k_bounce grid

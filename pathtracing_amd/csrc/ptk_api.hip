@@ -469,6 +469,11 @@ int ptk_set_option(const char* name, int64_t value) {
         g_tail_records = static_cast<uint32_t>(value);
         return PTK_OK;
     }
+    if (name && std::strcmp(name, "specialised_kernels") == 0) {
+        if (value != 0 && value != 1) return fail(PTK_ERR_INVALID, "ptk_set_option: specialised_kernels must be 0 or 1");
+        set_specialised_kernels(value != 0);
+        return PTK_OK;
+    }
     return fail(PTK_ERR_INVALID, std::string("ptk_set_option: unknown option ") + (name ? name : "(null)"));
 }
 
@@ -798,6 +803,8 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     dev.has_meshes = 0;
     dev.needs_uv = 0;
     dev.has_pass_through = 0;
+    dev.tables_fit_lds = (objects.size() + lights.size()) * sizeof(DevObject) + media.size() * sizeof(DevMedium) <=
+                         static_cast<size_t>(LDS_SCENE_DOUBLES) * sizeof(double);
     for (const DevMaterial& m : materials) {
         // Material::allow_direct_light (src/materials.cpp:55-60, :129-136)
         auto ior = [&](int medium) { return medium >= 0 ? media[static_cast<size_t>(medium)].ior : 1.0; };
@@ -1046,10 +1053,7 @@ int ptk_render_host(PtkScene* s, const PtkRenderJob* job, double* image, double*
 const char* ptk_scene_bounce_kernel(PtkScene* s) {
     static thread_local std::string name;
     if (!s) return "";
-    const DevScene& d = s->dev;
-    auto tf = [](bool v) { return v ? "true" : "false"; };
-    name = std::string("ptk::k_bounce<") + tf(d.has_triangles) + ", " + tf(d.needs_uv) + ", " + tf(d.has_meshes) + ", " +
-           tf(!d.has_meshes || d.has_pass_through) + ">";
+    name = bounce_kernel_name(s->dev);
     return name.c_str();
 }
 

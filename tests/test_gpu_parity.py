@@ -87,6 +87,29 @@ def test_results_do_not_depend_on_batch_size_or_knobs(scene_dirs, name):
             assert np.array_equal(a, b)
 
 
+# specialised_kernels = 0: every scene runs the general kernel variants (all features compiled in, scene tables read
+# from memory instead of their LDS copies), which is what scenes with more objects than the LDS copies hold get.
+@pytest.mark.parametrize("name", SCENES)
+def test_general_kernels_give_the_same_results(scene_dirs, name):
+    hs = pt.load_scene_directory(scene_dirs[name])
+    n = hs.settings.width * hs.settings.height
+    job = pt.make_job(0, n, 3, 0, 31)
+    for tail_records in (131072, 0):
+        pt.set_option("tail_records", tail_records)
+        try:
+            dev = pt.DeviceScene(hs)
+            specialised = dev.trace_samples(job)
+            assert dev.bounce_kernel().endswith("true>"), dev.bounce_kernel()
+            pt.set_option("specialised_kernels", 0)
+            assert dev.bounce_kernel().endswith("true, false>"), dev.bounce_kernel()
+            general = dev.trace_samples(job)
+        finally:
+            pt.set_option("specialised_kernels", 1)
+            pt.set_option("tail_records", 131072)
+        for a, b in zip(specialised, general):
+            assert np.array_equal(a, b)
+
+
 def test_pixel_subrange_equals_full_frame(scene_dirs):
     hs = pt.load_scene_directory(scene_dirs["zoo"])
     n = hs.settings.width * hs.settings.height

@@ -6,10 +6,8 @@ name=$1; shift
 cd "$(dirname "$0")/../pathtracing_amd/csrc"
 tmp=$(mktemp -d)
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -Idevice -I. $*"
-hipcc $F -c device/kernels.hip -o $tmp/kernels.o &
-hipcc $F -c ptk_api.hip -o $tmp/ptk_api.o &
-hipcc $F -c device/denoise.hip -o $tmp/denoise.o &
-wait
-hipcc --offload-arch=gfx950 -shared -fPIC $tmp/kernels.o $tmp/denoise.o $tmp/ptk_api.o build/bvh_builder.o -o ../libptk_$name.so -lpthread
+SOURCES="device/kernels.hip device/denoise.hip ptk_api.hip $(ls device/variants/*.hip)"
+printf '%s\n' $SOURCES | xargs -P 8 -I{} sh -c "hipcc $F -c {} -o $tmp/\$(basename {} .hip).o"
+hipcc --offload-arch=gfx950 -shared -fPIC $tmp/*.o build/bvh_builder.o -o ../libptk_$name.so -lpthread
 rm -rf $tmp
 echo built pathtracing_amd/libptk_$name.so
