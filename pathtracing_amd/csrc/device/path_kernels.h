@@ -106,21 +106,23 @@ PTK_DEV void camera_ray(const DevScene& sc, uint32_t pixel, Rng& rng, V3& org, V
 }
 
 // ---- record access ------------------------------------------------------------------------------
-// A plane's address is uniform (scalar arithmetic); the record index enters as a 32-bit byte offset.
-PTK_DEV char* plane_ptr(const PathPool& p, int plane) {
-    return p.base + static_cast<uint64_t>(plane) * p.plane_bytes;
+// Element `plane` of record i lies at base + record_offset(i) + plane * RECORD_PLANE_STRIDE: one uniform
+// base, one 32-bit per-lane offset shared by the ten planes, and the plane as an immediate offset of the
+// load or store.
+PTK_DEV uint32_t record_offset(uint32_t i) {
+    return (i / RECORD_TILE) * RECORD_TILE_BYTES + (i % RECORD_TILE) * 16u;
 }
 PTK_DEV double2 ld2(const PathPool& p, int plane, uint32_t i) {
-    return *reinterpret_cast<const double2*>(plane_ptr(p, plane) + i * 16u);
+    return *reinterpret_cast<const double2*>(p.base + record_offset(i) + plane * RECORD_PLANE_STRIDE);
 }
 PTK_DEV void st2(const PathPool& p, int plane, uint32_t i, double a, double b) {
-    *reinterpret_cast<double2*>(plane_ptr(p, plane) + i * 16u) = make_double2(a, b);
+    *reinterpret_cast<double2*>(p.base + record_offset(i) + plane * RECORD_PLANE_STRIDE) = make_double2(a, b);
 }
 PTK_DEV uint4 ldu4(const PathPool& p, int plane, uint32_t i) {
-    return *reinterpret_cast<const uint4*>(plane_ptr(p, plane) + i * 16u);
+    return *reinterpret_cast<const uint4*>(p.base + record_offset(i) + plane * RECORD_PLANE_STRIDE);
 }
 PTK_DEV void stu4(const PathPool& p, int plane, uint32_t i, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-    *reinterpret_cast<uint4*>(plane_ptr(p, plane) + i * 16u) = make_uint4(a, b, c, d);
+    *reinterpret_cast<uint4*>(p.base + record_offset(i) + plane * RECORD_PLANE_STRIDE) = make_uint4(a, b, c, d);
 }
 
 // The path ended: its radiance goes to the per-sample results.
@@ -331,6 +333,38 @@ PTK_DEV Record load_record(const PathPool& p, uint32_t i) {
     r.cc = ld2(p, PL_COL, i);
     r.hit = ldu4(p, PL_HIT, i);
     r.ids = ldu4(p, PL_IDS, i);
+    return r;
+}
+
+// Record prefetch through LDS: global_load_lds moves 16 bytes per lane from memory straight into LDS
+// (lane l of the wave writes dst + 16 l; dst is wave-uniform), without occupying registers while the
+// data is on its way.  A wave stages its own 64 records, plane by plane, and reads them back at the
+// top of the next round; nothing is shared between waves, so the only synchronisation is the wait for
+// the loads before the staging array is read.
+typedef __attribute__((address_space(3))) void* LdsVoidPtr;
+typedef const __attribute__((address_space(1))) void* GlobalVoidPtr;
+PTK_DEV void request_record(const PathPool& p, uint32_t i, double2* wave_stage) {
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the reads of the record staged before have returned
+#pragma unroll
+    for (int plane = 0; plane < N_PLANES; plane++)
+        __builtin_amdgcn_global_load_lds((GlobalVoidPtr) (p.base + record_offset(i) + plane * RECORD_PLANE_STRIDE), (LdsVoidPtr) (wave_stage + plane * BLOCK), 16, 0, 0);
+}
+PTK_DEV Record staged_record(const double2* stage) {
+    // vmcnt(0): every load this wave has requested, the ones into LDS included, has arrived.  Written out
+    // because the compiler's own wait-count insertion was seen to leave it out in the largest kernels.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    const double2* mine = stage + threadIdx.x;
+    Record r;
+    r.r0 = mine[PL_RAY0 * BLOCK];
+    r.r1 = mine[PL_RAY1 * BLOCK];
+    r.r2 = mine[PL_RAY2 * BLOCK];
+    r.t0 = mine[PL_THR0 * BLOCK];
+    r.t1 = mine[PL_THR1 * BLOCK];
+    r.v0 = mine[PL_SAV0 * BLOCK];
+    r.v1 = mine[PL_SAV1 * BLOCK];
+    r.cc = mine[PL_COL * BLOCK];
+    r.hit = *reinterpret_cast<const uint4*>(mine + PL_HIT * BLOCK);
+    r.ids = *reinterpret_cast<const uint4*>(mine + PL_IDS * BLOCK);
     return r;
 }
 
@@ -629,7 +663,13 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
                                                                                       uint32_t* block_counts, uint32_t count_stride,
                                                                                       unsigned long long* statistics, DeferQueues queues) {
     // DEFER: only the later segments of a visibility march walk a hierarchy here, and only if PASS
-    __shared__ StackEntry lds_stack[TRIS && (!DEFER || PASS) ? LDS_STACK_DEPTH * BLOCK : 1];
+    constexpr bool STACK = TRIS && (!DEFER || PASS);
+    __shared__ StackEntry lds_stack[STACK ? LDS_STACK_DEPTH * BLOCK : 1];
+    // Kernels without a traversal stack have the LDS to stage the next round's records there (STAGE);
+    // the others prefetch them into registers.
+    constexpr bool STAGE = !STACK;
+    __shared__ double2 lds_record[STAGE ? N_PLANES * BLOCK : 1];
+    double2* const wave_stage = lds_record + 64 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
     __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
     __shared__ uint32_t queue_counts[BLOCK / 64][2];
@@ -663,12 +703,20 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
         uint32_t qi = threadIdx.x;
         Record cur{};
         uint32_t src = qi < n ? list[first + qi] : 0u;
-        if (qi < n) cur = load_record(in, src);
+        if (qi < n) {
+            if (STAGE) request_record(in, src, wave_stage);
+            else cur = load_record(in, src);
+        }
         uint32_t src_next = qi + BLOCK < n ? list[first + qi + BLOCK] : 0u;
         for (uint32_t r = 0; r * BLOCK < n; r++, qi += BLOCK) {
             const bool have = qi < n, have_next = qi + BLOCK < n;
             const uint32_t dst = first + qi;
             int new_cls = -1;
+            if (STAGE && have) cur = staged_record(lds_record);
+            // The list entry requested a round ago is consumed here on every path: were it still on its way
+            // on some path when its register is reused below, the wait for it would be placed after the
+            // record requests of this round and would wait for them as well (loads return in order).
+            asm volatile("" : : "v"(src_next));
             Record nxt{};
             uint32_t src_after = 0;
             RayState rays[2];
@@ -679,8 +727,13 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
                 const bool alive = shade_record<TRIS, UV>(sc, b, res, cur, cls, v);
                 PTK_STAMP(0)
 
-                // request the next round's record and the list entry of the one after
-                if (have_next) nxt = load_record(in, src_next);
+                // Request the next round's record and the list entry of the one after.  Not earlier: registers
+                // would be held all through shading, and the compiler makes every read of the scene tables in
+                // LDS wait for outstanding loads into LDS; the object scan that follows reads none.
+                if (have_next) {
+                    if (STAGE) request_record(in, src_next, wave_stage);
+                    else nxt = load_record(in, src_next);
+                }
                 if (qi + 2 * BLOCK < n) src_after = list[first + qi + 2 * BLOCK];
 
                 // the shadow ray of the connection and the extension ray leave the vertex together
@@ -736,7 +789,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
 #pragma unroll
             for (int c = 0; c < N_CLASSES; c++)
                 if ((sc.class_mask >> c) & 1u) my_counts[c] += static_cast<uint32_t>(__popcll(__ballot(new_cls == c)));
-            cur = nxt;
+            if (!STAGE) cur = nxt;
             src = src_next;
             src_next = src_after;
         }

@@ -152,12 +152,13 @@ constexpr int LDS_SCENE_DOUBLES = 4096;
 constexpr int N_STATISTICS = 8;         // values per statistics slot (see kernels.hip)
 constexpr int STATISTICS_SLOTS = 8192; // per-block slots = the largest k_bounce grid
 
-// Path records live in two pools used ping-pong.  A pool is a set of planes of 16-byte elements
-// (plane p of record i at base + p * plane_bytes + 16 * i), so a wave reads or writes 1 KiB of
-// consecutive memory per instruction and every record is reached from one base pointer plus a
-// 32-bit offset.  Each bounce's kernels read the records of their class through the sorted index
-// list and write the updated records to the other pool at the list position, so the records of
-// the paths still in flight are always packed at the front of the current pool.
+// Path records live in two pools used ping-pong.  A record is ten 16-byte elements ("planes", below).  A pool
+// is laid out in tiles of RECORD_TILE records: within a tile, plane p of the 16 records is 256 consecutive
+// bytes at p * 256, so a wave's load of one plane reads four runs of 256 bytes (whole cache lines), and all ten
+// planes of a record are reached from one base pointer and one 32-bit offset, the plane being an immediate
+// offset in the instruction.  Each bounce's kernels read the records of their class through the sorted index
+// list and write the updated records to the other pool at the list position, so the records of the paths still
+// in flight are always packed at the front of the current pool.
 enum Plane : int {
     PL_RAY0 = 0, // origin.x, origin.y
     PL_RAY1,     // origin.z, direction.x
@@ -171,10 +172,12 @@ enum Plane : int {
     PL_IDS,      // uint32 x 4: next random-number counter, object index, triangle index (global leaf order), unused
     N_PLANES
 };
+constexpr uint32_t RECORD_TILE = 16;                                  // records per tile
+constexpr uint32_t RECORD_PLANE_STRIDE = RECORD_TILE * 16;            // bytes between planes within a tile
+constexpr uint32_t RECORD_TILE_BYTES = N_PLANES * RECORD_PLANE_STRIDE; // 2560
 struct PathPool {
-    char* base;
-    uint64_t plane_bytes; // capacity * 16
-    uint8_t* cls;         // per record: class of the vertex to shade (0..7), or CLASS_DONE
+    char* base;   // capacity (a multiple of RECORD_TILE) * 160 bytes
+    uint8_t* cls; // per record: class of the vertex to shade (0..7), or CLASS_DONE
 };
 // flags: depth (13 bits) | ray type << 13 | has_hit_surface << 15 | medium << 16
 

@@ -188,11 +188,10 @@ int ensure_capacity(PtkScene* s, int64_t paths) {
     if (paths <= s->capacity) return PTK_OK;
     s->pool_buffers.free_all(); // the previous, smaller arrays
     s->capacity = 0;
-    const size_t n = (static_cast<size_t>(paths) + 255) & ~static_cast<size_t>(255); // planes stay 4 KiB aligned
+    const size_t n = (static_cast<size_t>(paths) + 255) & ~static_cast<size_t>(255); // whole record tiles
     DeviceBuffers& b = s->pool_buffers;
     for (PathPool& pool : s->pools) {
-        pool.plane_bytes = n * 16;
-        HIP_TRY(b.alloc(&pool.base, pool.plane_bytes * N_PLANES));
+        HIP_TRY(b.alloc(&pool.base, n * N_PLANES * 16));
         HIP_TRY(b.alloc(&pool.cls, n));
     }
     HIP_TRY(b.alloc(&s->results.color, n * 4));
@@ -509,7 +508,9 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
 
     std::unique_ptr<PtkScene> s(new PtkScene());
     s->settings = d->settings;
-    s->max_paths = max_paths_in_flight > 0 ? max_paths_in_flight : DEFAULT_MAX_PATHS;
+    // records are addressed with 32-bit byte offsets (160 bytes each): at most 2^24 in flight; larger jobs are
+    // cut into batches anyway
+    s->max_paths = max_paths_in_flight > 0 ? std::min(max_paths_in_flight, DEFAULT_MAX_PATHS) : DEFAULT_MAX_PATHS;
     DevScene& dev = s->dev;
     DeviceBuffers& buf = s->scene_buffers;
 
