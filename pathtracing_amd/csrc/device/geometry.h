@@ -299,7 +299,7 @@ PTK_DEV void test_shape(const DevScene& sc, const DevShape& o, int index, const 
 #pragma unroll
         for (int k = 0; k < N; k++) {
             double ddn = -dot(rays[k].dir, nrm);
-            d[k] = shifted_dot_n / ddn;
+            d[k] = fdiv(shifted_dot_n, ddn); // a zero or tiny ddn is rejected below whatever the quotient
             success[k] = !(fabs(ddn) < EPSILON); // d >= EPSILON and d <= t_max are implied by accept_hit's tests
         }
         if (o.type == PTK_OBJ_RECTANGLE) {

@@ -89,7 +89,7 @@ PTK_DEV void camera_ray(const DevScene& sc, uint32_t pixel, Rng& rng, V3& org, V
         V3 focal_point = org + dir * t;
         V3 adjust;
         if (c.dof_mode == PTK_DOF_CIRCLE) {
-            double r = c.aperture / 2.0 * sqrt(rng.u01());
+            double r = c.aperture / 2.0 * fsqrt(rng.u01());
             double phi = rng.uniform(0, 2 * PI);
             double s, co;
             sincos(phi, &s, &co);

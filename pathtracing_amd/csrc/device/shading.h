@@ -235,7 +235,7 @@ PTK_DEV double object_light_pdf(const DevScene& sc, const DevObject& o, const V3
         double distance = len(from - v3(o.px, o.py, o.pz));
         if (distance <= o.radius) return 1.0 / (o.area * area_to_angle_factor<TRIS>(sc, o, surface_point, from, 0));
         double q = o.radius / distance;
-        double cos_theta_max = sqrt(1 - q * q);
+        double cos_theta_max = fsqrt(1 - q * q);
         return 1.0 / (2.0 * PI * (1 - cos_theta_max));
     }
     if (o.type == PTK_OBJ_PLANE) return 0.0; // :217-219
@@ -247,7 +247,7 @@ PTK_DEV double object_light_pdf(const DevScene& sc, const DevObject& o, const V3
 PTK_DEV V3 triangle_random_point(const TriHot& t, Rng& rng) { // :408-412
     double r1 = rng.u01();
     double r2 = rng.u01();
-    double s = sqrt(r1);
+    double s = fsqrt(r1);
     return v3(t.p1) * (1.0 - s) + v3(t.p2) * (s * (1.0 - r2)) + v3(t.p3) * (s * r2);
 }
 
@@ -280,15 +280,15 @@ PTK_DEV V3 random_light_point(const DevScene& sc, const DevObject& o, const V3& 
             return p;
         }
         double q = o.radius / distance;
-        double cos_theta_max = sqrt(1 - q * q);
+        double cos_theta_max = fsqrt(1 - q * q);
         pdf = 1.0 / (2.0 * PI * (1 - cos_theta_max));
         double r = rng.u01();
         double cos_theta = 1 + r * (cos_theta_max - 1);
-        double sin_theta = sqrt(1 - cos_theta * cos_theta);
+        double sin_theta = fsqrt(1 - cos_theta * cos_theta);
         double ds = distance * sin_theta;
-        double inner = distance * cos_theta - sqrt(o.radius * o.radius - ds * ds);
+        double inner = distance * cos_theta - fsqrt(o.radius * o.radius - ds * ds);
         double cos_alpha = (o.radius * o.radius + distance * distance - inner * inner) / (2.0 * distance * o.radius);
-        double sin_alpha = sqrt(1.0 - cos_alpha * cos_alpha);
+        double sin_alpha = fsqrt(1.0 - cos_alpha * cos_alpha);
         V3 x_hat, y_hat;
         V3 z_hat = normalize(from - centre);
         perpendicular_vectors(z_hat, x_hat, y_hat);
