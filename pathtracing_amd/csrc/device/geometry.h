@@ -78,19 +78,21 @@ struct StackEntry {
 // The LDS address space is part of the pointer type: through a generic pointer the pushes and pops
 // would be flat instructions, which take the slower path of the vector memory unit.
 typedef __attribute__((address_space(3))) StackEntry LdsStackEntry;
+// The entries beyond the LDS part live in an array of their own (the caller's, see make_stack): were it a member,
+// its run-time indexing would keep the whole struct, sp and the counters included, in scratch memory, and every
+// push and pop would go through memory for them.
 struct TraversalStack {
     LdsStackEntry* lds; // this thread's column: element d at lds[d * blockDim.x]
     int stride;
-    StackEntry spill[SPILL_STACK_DEPTH];
+    StackEntry* spill;  // [SPILL_STACK_DEPTH]
     int sp;
-    uint32_t nodes_visited = 0, triangles_tested = 0; // statistics of k_traverse
+    uint32_t nodes_visited, triangles_tested; // statistics of k_traverse
     PTK_DEV void push(int32_t node, float tnear) {
-        StackEntry e{node, tnear};
         if (sp < LDS_STACK_DEPTH) {
             lds[sp * stride].node = node;
             lds[sp * stride].tnear = tnear;
         }
-        else if (sp < LDS_STACK_DEPTH + SPILL_STACK_DEPTH) spill[sp - LDS_STACK_DEPTH] = e;
+        else if (sp < LDS_STACK_DEPTH + SPILL_STACK_DEPTH) spill[sp - LDS_STACK_DEPTH] = StackEntry{node, tnear};
         else return; // deeper than any tree the builder produces (its depth is bounded)
         sp++;
     }
@@ -124,78 +126,121 @@ PTK_DEV void sort_pair(float& ta, int32_t& ca, float& tb, int32_t& cb) {
     ca = c;
 }
 
-PTK_DEV void mesh_closest_hit(const DevScene& sc, int32_t bvh_root, int64_t first_tri, const V3& org, const V3& dir,
-                              const RayPrep& rp, double& t_best, int& prim_best, TraversalStack& st, float bound_abs,
-                              bool any_hit = false) {
-    if (bvh_root < 0) return;
+typedef float Float2 __attribute__((ext_vector_type(2))); // two children at a time: v_pk_add_f32 / v_pk_mul_f32
+
+// Next entry of the stack that can still hold something closer than t_best; BVH_EMPTY when there is none.
+PTK_DEV int32_t pop_closer(TraversalStack& st, double t_best) {
+    while (st.sp > 0) {
+        const StackEntry e = st.pop();
+        if (static_cast<double>(e.tnear) < t_best) return e.node;
+    }
+    return BVH_EMPTY;
+}
+
+// Per-ray constants of the fp32 slab test, two lanes wide (the same value in both halves).
+struct SlabRay {
+    Float2 nox, noy, noz; // -origin
+    Float2 ix, iy, iz;    // 1 / direction
+    Float2 px, py, pz;    // widening of each axis interval
+};
+PTK_DEV SlabRay slab_ray(const V3& org, const V3& dir, float bound_abs) {
     const float ox = static_cast<float>(org.x), oy = static_cast<float>(org.y), oz = static_cast<float>(org.z);
     const float idx = static_cast<float>(1.0 / dir.x), idy = static_cast<float>(1.0 / dir.y), idz = static_cast<float>(1.0 / dir.z);
     const float widen = 0x1p-22f;
     const float pad_x = widen * (fabsf(ox) + bound_abs) * fabsf(idx);
     const float pad_y = widen * (fabsf(oy) + bound_abs) * fabsf(idy);
     const float pad_z = widen * (fabsf(oz) + bound_abs) * fabsf(idz);
+    SlabRay r;
+    r.nox = Float2{-ox, -ox};
+    r.noy = Float2{-oy, -oy};
+    r.noz = Float2{-oz, -oz};
+    r.ix = Float2{idx, idx};
+    r.iy = Float2{idy, idy};
+    r.iz = Float2{idz, idz};
+    r.px = Float2{pad_x, pad_x};
+    r.py = Float2{pad_y, pad_y};
+    r.pz = Float2{pad_z, pad_z};
+    return r;
+}
+
+// One inner node (already in registers: `n`): tests its four boxes, pushes the children that can hold something
+// closer than t_best except the nearest, and returns the nearest (or the next entry of the stack when no child
+// qualifies).
+PTK_DEV int32_t visit_inner(const BvhNode4& n, const SlabRay& r, double t_best, TraversalStack& st) {
     const float FAR = __builtin_inff();
+    st.nodes_visited++;
+    float tn[4];
+    int32_t ch[4];
+#pragma unroll
+    for (int h = 0; h < 2; h++) { // children 2h and 2h + 1
+        const Float2 lx = {n.lo_x[2 * h], n.lo_x[2 * h + 1]}, hx = {n.hi_x[2 * h], n.hi_x[2 * h + 1]};
+        const Float2 ly = {n.lo_y[2 * h], n.lo_y[2 * h + 1]}, hy = {n.hi_y[2 * h], n.hi_y[2 * h + 1]};
+        const Float2 lz = {n.lo_z[2 * h], n.lo_z[2 * h + 1]}, hz = {n.hi_z[2 * h], n.hi_z[2 * h + 1]};
+        const Float2 ax = (lx + r.nox) * r.ix, bx = (hx + r.nox) * r.ix;
+        const Float2 ay = (ly + r.noy) * r.iy, by = (hy + r.noy) * r.iy;
+        const Float2 az = (lz + r.noz) * r.iz, bz = (hz + r.noz) * r.iz;
+        const Float2 near_x = __builtin_elementwise_min(ax, bx) - r.px, far_x = __builtin_elementwise_max(ax, bx) + r.px;
+        const Float2 near_y = __builtin_elementwise_min(ay, by) - r.py, far_y = __builtin_elementwise_max(ay, by) + r.py;
+        const Float2 near_z = __builtin_elementwise_min(az, bz) - r.pz, far_z = __builtin_elementwise_max(az, bz) + r.pz;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int c = 2 * h + k;
+            float lo = fmaxf(fmaxf(0.0f, near_x[k]), fmaxf(near_y[k], near_z[k]));
+            float hi = fminf(far_x[k], fminf(far_y[k], far_z[k]));
+            lo *= 1.0f - 0x1p-21f;
+            hi *= 1.0f + 0x1p-21f;
+            ch[c] = n.child[c];
+            const bool ok = ch[c] != BVH_EMPTY && hi >= lo && static_cast<double>(lo) < t_best;
+            tn[c] = ok ? lo : FAR;
+        }
+    }
+    sort_pair(tn[0], ch[0], tn[1], ch[1]);
+    sort_pair(tn[2], ch[2], tn[3], ch[3]);
+    sort_pair(tn[0], ch[0], tn[2], ch[2]);
+    sort_pair(tn[1], ch[1], tn[3], ch[3]);
+    sort_pair(tn[1], ch[1], tn[2], ch[2]);
+    if (tn[3] < FAR) st.push(ch[3], tn[3]);
+    if (tn[2] < FAR) st.push(ch[2], tn[2]);
+    if (tn[1] < FAR) st.push(ch[1], tn[1]);
+    return tn[0] < FAR ? ch[0] : pop_closer(st, t_best);
+}
+
+// One leaf: the exact test of its triangles; returns whether one of them became the closest hit.
+PTK_DEV bool visit_leaf(const DevScene& sc, int32_t leaf, int64_t first_tri, const V3& org, const RayPrep& rp, double& t_best,
+                        int& prim_best, TraversalStack& st) {
+    const uint32_t code = static_cast<uint32_t>(~leaf);
+    const int64_t first = first_tri + (code >> 3);
+    const int count = static_cast<int>(code & 7u) + 1;
+    st.triangles_tested += count;
+    bool found = false;
+    for (int i = 0; i < count; i++) {
+        double d;
+        if (triangle_hit(sc.tri_hot[first + i], org, rp, t_best, d) && d > EPSILON && d < t_best) {
+            t_best = d;
+            prim_best = static_cast<int>(first + i);
+            found = true;
+        }
+    }
+    return found;
+}
+
+// The walk alternates between two loops: down through inner nodes until the lane holds a leaf, then through
+// leaves until it holds an inner node again.  The lanes of a wave then execute the box tests together and the
+// triangle tests together.
+PTK_DEV void mesh_closest_hit(const DevScene& sc, int32_t bvh_root, int64_t first_tri, const V3& org, const V3& dir,
+                              const RayPrep& rp, double& t_best, int& prim_best, TraversalStack& st, float bound_abs,
+                              bool any_hit = false) {
+    if (bvh_root < 0) return;
+    const SlabRay r = slab_ray(org, dir, bound_abs);
     st.sp = 0;
     int32_t node = bvh_root;
     for (;;) {
-        if (node >= 0) {
-            st.nodes_visited++;
-            const BvhNode4& n = sc.nodes[node];
-            float tn[4];
-            int32_t ch[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                float t0 = (n.lo_x[c] - ox) * idx, t1 = (n.hi_x[c] - ox) * idx;
-                float lo = fmaxf(0.0f, fminf(t0, t1) - pad_x), hi = fmaxf(t0, t1) + pad_x;
-                t0 = (n.lo_y[c] - oy) * idy;
-                t1 = (n.hi_y[c] - oy) * idy;
-                lo = fmaxf(lo, fminf(t0, t1) - pad_y);
-                hi = fminf(hi, fmaxf(t0, t1) + pad_y);
-                t0 = (n.lo_z[c] - oz) * idz;
-                t1 = (n.hi_z[c] - oz) * idz;
-                lo = fmaxf(lo, fminf(t0, t1) - pad_z);
-                hi = fminf(hi, fmaxf(t0, t1) + pad_z);
-                lo *= 1.0f - 0x1p-21f;
-                hi *= 1.0f + 0x1p-21f;
-                ch[c] = n.child[c];
-                const bool ok = ch[c] != BVH_EMPTY && hi >= lo && static_cast<double>(lo) < t_best;
-                tn[c] = ok ? lo : FAR;
-            }
-            sort_pair(tn[0], ch[0], tn[1], ch[1]);
-            sort_pair(tn[2], ch[2], tn[3], ch[3]);
-            sort_pair(tn[0], ch[0], tn[2], ch[2]);
-            sort_pair(tn[1], ch[1], tn[3], ch[3]);
-            sort_pair(tn[1], ch[1], tn[2], ch[2]);
-            if (tn[3] < FAR) st.push(ch[3], tn[3]);
-            if (tn[2] < FAR) st.push(ch[2], tn[2]);
-            if (tn[1] < FAR) st.push(ch[1], tn[1]);
-            if (tn[0] < FAR) {
-                node = ch[0];
-                continue;
-            }
+        while (node >= 0) node = visit_inner(sc.nodes[node], r, t_best, st);
+        while (node < 0 && node != BVH_EMPTY) {
+            if (visit_leaf(sc, node, first_tri, org, rp, t_best, prim_best, st) && any_hit) return;
+            node = pop_closer(st, t_best);
         }
-        else { // leaf
-            const uint32_t code = static_cast<uint32_t>(~node);
-            const int64_t first = first_tri + (code >> 3);
-            const int count = static_cast<int>(code & 7u) + 1;
-            st.triangles_tested += count;
-            for (int i = 0; i < count; i++) {
-                double d;
-                if (triangle_hit(sc.tri_hot[first + i], org, rp, t_best, d) && d > EPSILON && d < t_best) {
-                    t_best = d;
-                    prim_best = static_cast<int>(first + i);
-                }
-            }
-            if (any_hit && prim_best >= 0) return;
-        }
-        for (;;) { // next entry of the stack that can still hold something closer
-            if (st.sp == 0) return;
-            const StackEntry e = st.pop();
-            if (static_cast<double>(e.tnear) < t_best) {
-                node = e.node;
-                break;
-            }
-        }
+        if (node == BVH_EMPTY) return;
     }
 }
 

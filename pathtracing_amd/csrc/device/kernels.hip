@@ -120,39 +120,104 @@ __global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathPool pool, const BinI
         if (classes[r] >= 0) list_out[counts[r][wave][classes[r]] + below[r]] = first + r * BLOCK + threadIdx.x;
 }
 
-// Closest triangle for every queued ray, one ray per lane: the meshes of the scene in object order,
-// each hierarchy walked with the shrinking t_max.
+// Closest triangle for every queued ray: the meshes of the scene in object order, each hierarchy walked with
+// the shrinking t_max.  One ray per lane, and a wave that has lost enough of its rays takes new ones from the
+// queue: the number of nodes a ray visits varies widely (a few for most, hundreds for rays that graze a mesh),
+// and a wave that kept its 64 rays until the last one finished ran mostly empty.  The grid is sized to fill the
+// device once; every wave leaves when the queue is empty and its own rays are done.
+// queues.counters: [0] rays queued, [2] next ray to hand out (zero at launch).
+constexpr int REFILL_LANES = 16; // idle lanes at which a wave fetches
+
 __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_WAVES) void k_traverse(DevScene sc, DeferQueues queues,
                                                                                            unsigned long long* statistics) {
     __shared__ StackEntry lds_stack[LDS_STACK_DEPTH * BLOCK];
     __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
-    TraversalStack st = make_stack(lds_stack);
+    PTK_TRAVERSAL_STACK(st, lds_stack);
     const uint32_t n = queues.counters[0];
-    if (blockIdx.x * BLOCK >= n) return;
-    const PTK_CONSTANT DevShape* shapes = (const PTK_CONSTANT DevShape*) sc.shapes;
+    // the list of meshes, in LDS when it fits: a ray consults it whenever it moves on to its next mesh
+    __shared__ DevMeshRef lds_meshes[TRAVERSE_LDS_MESHES];
+    const bool meshes_in_lds = sc.n_meshes <= TRAVERSE_LDS_MESHES;
+    if (meshes_in_lds) {
+        for (int i = threadIdx.x; i < sc.n_meshes; i += BLOCK) lds_meshes[i] = sc.meshes[i];
+        __syncthreads();
+    }
     uint32_t stat[N_STATISTICS] = {}; // [0] rays, [1] nodes visited, [2] triangles tested
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
-        const RayRequest q = queues.rays[i];
-        const V3 org = v3(q.ox, q.oy, q.oz), dir = v3(q.dx, q.dy, q.dz);
-        const RayPrep rp = prepare_ray(dir);
-        RayResult best{q.limit, -1, 0};
-        stat[0]++;
-        for (int o = 0; o < sc.n_objects; o++) {
-            if (shapes[o].type != PTK_OBJ_MESH) continue;
-            int prim = -1;
-            // A shadow ray (even slot) is blocked by any triangle of a mesh that lets no connection
-            // through: the march ends in black whichever triangle it meets first.
-            const bool any_hit = (q.slot & 1u) == 0 && shapes[o].f[6] != 0;
-            DevShape shape;
-            load_shape(shapes + o, shape);
-            mesh_closest_hit(sc, shape.bvh_root, shape.first_tri, org, dir, rp, best.t, prim, st, mesh_bound_abs(shape), any_hit);
-            if (prim >= 0) {
-                best.obj = o;
-                best.prim = prim;
-                if (any_hit) break;
+    bool exhausted = false;           // wave-uniform: the queue has been handed out completely
+    bool has_ray = false;
+    V3 org = v3(0.0);
+    RayPrep rp{};
+    SlabRay slab{};
+    RayResult best{INF, -1, 0};
+    uint32_t slot = 0;
+    int mesh = 0, object = 0;   // the mesh being walked: position in the list of meshes, object index
+    int64_t first_tri = 0;
+    bool any_hit = false;
+    int32_t node = BVH_EMPTY;   // BVH_EMPTY: the walk of the current mesh is over (or has not begun)
+    for (;;) {
+        // new rays for the idle lanes, once there are enough of them
+        const unsigned long long idle = __ballot(!has_ray);
+        const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle));
+        if (!exhausted && n_idle >= REFILL_LANES) {
+            uint32_t base = 0;
+            if (lanes_below(idle) == 0 && !has_ray) base = atomicAdd(queues.counters + 2, n_idle); // the first idle lane
+            base = __shfl(base, __ffsll(static_cast<long long>(idle)) - 1);
+            if (!has_ray) {
+                const uint32_t i = base + lanes_below(idle);
+                if (i < n) {
+                    const RayRequest q = queues.rays[i];
+                    org = v3(q.ox, q.oy, q.oz);
+                    const V3 dir = v3(q.dx, q.dy, q.dz);
+                    rp = prepare_ray(dir);
+                    slab = slab_ray(org, dir, sc.mesh_bound_abs);
+                    best = RayResult{q.limit, -1, 0};
+                    slot = q.slot;
+                    mesh = -1;
+                    node = BVH_EMPTY;
+                    has_ray = true;
+                    stat[0]++;
+                }
+            }
+            exhausted = base + n_idle >= n;
+        }
+        if (__ballot(has_ray) == 0) {
+            if (exhausted) break;
+            continue; // all 64 lanes are idle: the next pass fetches
+        }
+        // lanes between meshes: on to the next mesh of the ray, or the ray is finished
+        if (has_ray && node == BVH_EMPTY) {
+            mesh++;
+            if (mesh < sc.n_meshes) {
+                const DevMeshRef m = meshes_in_lds ? lds_meshes[mesh] : sc.meshes[mesh];
+                object = m.object;
+                node = m.bvh_root;
+                first_tri = m.first_tri;
+                // A shadow ray (even slot) is blocked by any triangle of a mesh that lets no connection
+                // through: the march ends in black whichever triangle it meets first.
+                any_hit = (slot & 1u) == 0 && m.opaque != 0;
+                st.sp = 0;
+            }
+            else {
+                queues.results[slot] = best;
+                has_ray = false;
             }
         }
-        queues.results[q.slot] = best;
+        // One descent through inner nodes, then the leaves it led to.  (Stepping the lanes that hold inner nodes and
+        // the lanes that hold leaves separately, whichever kind is more numerous first, doubled the share of active
+        // lanes per instruction and was slower: the walk is bound by the vector memory pipeline, not by arithmetic.)
+        while (node >= 0) node = visit_inner(sc.nodes[node], slab, best.t, st);
+        while (node < 0 && node != BVH_EMPTY) {
+            int prim = -1;
+            const bool found = visit_leaf(sc, node, first_tri, org, rp, best.t, prim, st);
+            node = pop_closer(st, best.t);
+            if (found) {
+                best.obj = object;
+                best.prim = prim;
+                if (any_hit) { // nothing else matters for this ray
+                    mesh = sc.n_meshes;
+                    node = BVH_EMPTY;
+                }
+            }
+        }
     }
     stat[1] = st.nodes_visited;
     stat[2] = st.triangles_tested;
@@ -242,7 +307,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_samples(BatchParams b, SampleR
 __global__ __launch_bounds__(BLOCK) void k_primary(DevScene sc, BatchParams b, int32_t* object_index, int32_t* primitive_index,
                                                    double* distance, double* position, double* normal) {
     __shared__ StackEntry lds_stack[LDS_STACK_DEPTH * BLOCK];
-    TraversalStack st = make_stack(lds_stack);
+    PTK_TRAVERSAL_STACK(st, lds_stack);
     for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < b.n_pixels; p += gridDim.x * BLOCK) {
         const uint32_t pixel = static_cast<uint32_t>(b.start_idx) + p;
         Rng rng{rng_key(b.seed, pixel, b.sample_offset), 0};
@@ -349,7 +414,7 @@ void launch_bounce(hipStream_t s, uint32_t bound, uint32_t rounds, const DevScen
                    uint32_t count_stride, unsigned long long* statistics, const DeferQueues& queues) {
     const dim3 grid(min(chunk_blocks(bound, rounds), static_cast<uint32_t>(STATISTICS_SLOTS)));
     const Variant v = variant_of(sc);
-    if (v.defer) (void) hipMemsetAsync(queues.counters, 0, 2 * sizeof(uint32_t), s);
+    if (v.defer) (void) hipMemsetAsync(queues.counters, 0, 4 * sizeof(uint32_t), s);
 #define PTK_CASE(T, U, D, P, C)                                                                                                    \
     if (v.tris == T && v.uv == U && v.defer == D && v.pass == P && v.cache == C)                                                   \
         return launch_bounce_variant<T, U, D, P, C>(s, grid, sc, b, in, out, res, list, info, rounds, block_counts, count_stride, \
@@ -388,7 +453,9 @@ void launch_tail(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchP
 }
 
 void launch_traverse(hipStream_t s, uint32_t bound, const DevScene& sc, const DeferQueues& queues, unsigned long long* statistics) {
-    const dim3 grid(min((2 * bound + BLOCK - 1) / BLOCK + 1, static_cast<uint32_t>(STATISTICS_SLOTS)));
+    // enough blocks to fill the device once (256 CUs, PTK_TRAVERSE_WAVES waves per SIMD, four waves per block)
+    const uint32_t resident = 256u * PTK_TRAVERSE_WAVES;
+    const dim3 grid(min((2 * bound + BLOCK - 1) / BLOCK + 1, resident));
     hipLaunchKernelGGL(k_traverse, grid, dim3(BLOCK), 0, s, sc, queues, statistics);
 }
 

@@ -44,18 +44,24 @@ constexpr int BLOCK = 256;
 #define PTK_BOUNCE_UV_WAVES 2
 #endif
 #ifndef PTK_TRAVERSE_WAVES
-#define PTK_TRAVERSE_WAVES 6
+#define PTK_TRAVERSE_WAVES 5
 #endif
 #define PTK_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 static_assert(BLOCK == BIN_BLOCK, "k_extend and the bin kernels share their block geometry");
 
-PTK_DEV TraversalStack make_stack(StackEntry* lds) {
+PTK_DEV TraversalStack make_stack(StackEntry* lds, StackEntry* spill) {
     TraversalStack st;
     st.lds = (LdsStackEntry*) lds + threadIdx.x;
     st.stride = blockDim.x;
+    st.spill = spill;
     st.sp = 0;
+    st.nodes_visited = st.triangles_tested = 0;
     return st;
 }
+// declares the traversal stack `st` of a kernel over its LDS array
+#define PTK_TRAVERSAL_STACK(st, lds_array)        \
+    StackEntry st##_spill[SPILL_STACK_DEPTH];     \
+    TraversalStack st = make_stack(lds_array, st##_spill)
 
 PTK_DEV void sample_coordinates(const BatchParams& b, uint32_t sid, uint32_t& pixel, uint32_t& sample) {
     uint32_t s = sid / b.n_pixels;
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, 
                                                     uint32_t* block_counts, uint32_t count_stride) {
     __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1];
     __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
-    TraversalStack st = make_stack(lds_stack);
+    PTK_TRAVERSAL_STACK(st, lds_stack);
     if (blockIdx.x == 0 && threadIdx.x < N_CLASSES) {
         first_info->start[threadIdx.x] = threadIdx.x == 0 ? 0u : b.n_paths;
         first_info->count[threadIdx.x] = threadIdx.x == 0 ? b.n_paths : 0u;
@@ -674,7 +680,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
     __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
     __shared__ uint32_t queue_counts[BLOCK / 64][2];
     __shared__ uint32_t queue_base[2];
-    TraversalStack st = make_stack(lds_stack);
+    PTK_TRAVERSAL_STACK(st, lds_stack);
     __shared__ double lds_scene[CACHE ? LDS_SCENE_DOUBLES : 1];
     const DevScene sc = stage_scene<CACHE>(sc_global, lds_scene);
     const ChunkTable table = chunk_table(info, rounds * BLOCK);
@@ -809,7 +815,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
                                                                                     const BinInfo* info, unsigned long long* statistics) {
     __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1];
     __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
-    TraversalStack st = make_stack(lds_stack);
+    PTK_TRAVERSAL_STACK(st, lds_stack);
     const uint32_t n = info->total;
     if (blockIdx.x * BLOCK >= n) return;
     __shared__ double lds_scene[CACHE ? LDS_SCENE_DOUBLES : 1];
@@ -848,7 +854,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
                                                                                              DeferQueues queues) {
     __shared__ StackEntry lds_stack[PASS ? LDS_STACK_DEPTH * BLOCK : 1];
     __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
-    TraversalStack st = make_stack(lds_stack);
+    PTK_TRAVERSAL_STACK(st, lds_stack);
     const uint32_t n = queues.counters[1];
     if (blockIdx.x * BLOCK >= n) return;
     __shared__ double lds_scene[CACHE ? LDS_SCENE_DOUBLES : 1];

@@ -85,6 +85,15 @@ struct DevShape {
 };
 static_assert(sizeof(DevShape) == 128, "DevShape is read as two 64-byte scalar loads");
 
+// The meshes of the scene that have triangles, in object order: what k_traverse needs to start a walk.
+struct DevMeshRef { // 16 bytes
+    int32_t object;    // index in the object table
+    int32_t bvh_root;
+    int32_t first_tri;
+    int32_t opaque;    // no connection to a light passes through this mesh (DevShape::f[6])
+};
+constexpr int TRAVERSE_LDS_MESHES = 256; // entries of the list of meshes k_traverse keeps in LDS
+
 struct TriHot { // vertices, fp64
     double p1[3], p2[3], p3[3];
 };
@@ -143,7 +152,10 @@ struct DevScene {
     const BvhNode4* nodes;
     const double* light_cumulative_area; // per mesh light: cumulative areas in OBJ face order
     const int32_t* light_tri_index;      // per mesh light: root-sorted position -> triangle (leaf order)
+    const DevMeshRef* meshes;            // [n_meshes]
+    int32_t n_meshes, _pad2;
     uint32_t class_mask;                 // material classes present in the scene (+ scatter bit)
+    float mesh_bound_abs;                // largest absolute coordinate of any mesh's bounds, rounded up
 };
 
 // LDS every block of the shading kernels sets aside for copies of the object, light and medium tables
@@ -206,7 +218,7 @@ struct DeferQueues {
     RayRequest* rays;
     RayResult* results;       // [2 * capacity], indexed by RayRequest::slot
     DeferredVertex* vertices;
-    uint32_t* counters;       // [0] rays queued, [1] vertices queued
+    uint32_t* counters;       // [4]: [0] rays queued, [1] vertices queued, [2] rays handed out by k_traverse
 };
 
 // Per-sample results (PixelData, app/pathtracer.cpp:20-24), indexed by the sample's batch index

@@ -202,7 +202,7 @@ int ensure_capacity(PtkScene* s, int64_t paths) {
         HIP_TRY(b.alloc(&s->queues.rays, 2 * n));
         HIP_TRY(b.alloc(&s->queues.results, 2 * n));
         HIP_TRY(b.alloc(&s->queues.vertices, n));
-        HIP_TRY(b.alloc(&s->queues.counters, 2));
+        HIP_TRY(b.alloc(&s->queues.counters, 4));
     }
     s->count_stride = (chunk_capacity(static_cast<uint32_t>(n)) + 3u) & ~3u; // one entry per chunk; rows stay 16-byte aligned
     HIP_TRY(b.alloc(&s->block_counts, static_cast<size_t>(s->count_stride) * N_CLASSES));
@@ -801,6 +801,10 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
             std::memcpy(sh.f, v, sizeof(v));
         }
     }
+    dev.mesh_bound_abs = 0;
+    for (const DevShape& sh : shapes)
+        if (sh.type == PTK_OBJ_MESH && sh.bvh_root >= 0)
+            for (int k = 0; k < 6; k++) dev.mesh_bound_abs = std::max(dev.mesh_bound_abs, static_cast<float>(std::fabs(sh.f[k])) * (1.0f + 0x1p-20f));
     dev.has_meshes = 0;
     dev.needs_uv = 0;
     dev.has_pass_through = 0;
@@ -842,6 +846,12 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     HIP_TRY(buf.upload(&dev.tri_hot, tri_hot));
     HIP_TRY(buf.upload(&dev.tri_cold, tri_cold));
     HIP_TRY(buf.upload(&dev.nodes, nodes));
+    std::vector<DevMeshRef> mesh_refs; // what k_traverse needs to start the walk of each mesh
+    for (size_t i = 0; i < shapes.size(); i++)
+        if (shapes[i].type == PTK_OBJ_MESH && shapes[i].bvh_root >= 0)
+            mesh_refs.push_back(DevMeshRef{static_cast<int32_t>(i), shapes[i].bvh_root, shapes[i].first_tri, shapes[i].f[6] != 0 ? 1 : 0});
+    dev.n_meshes = static_cast<int32_t>(mesh_refs.size());
+    HIP_TRY(buf.upload(&dev.meshes, mesh_refs));
     HIP_TRY(buf.upload(&dev.light_cumulative_area, light_area));
     HIP_TRY(buf.upload(&dev.light_tri_index, light_tri));
     HIP_TRY(buf.alloc(&s->d_info, 2));

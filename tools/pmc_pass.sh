@@ -1,5 +1,6 @@
 #!/bin/bash
 # One rocprofv3 counter pass over a short bench run (GPU box).  usage: tools/pmc_pass.sh <tag> "<counters>" [bench flags...]
+# PTK_DEVICE_LIBRARY in the environment selects the device library build, as for bench.py itself.
 set -e
 tag=$1; counters=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$PWD}
