@@ -217,6 +217,33 @@ def test_settings_variations_match_oracle(scene_dirs, ob, name, overrides):
             assert frac >= 0.999, f"{name} {overrides} {what}: only {frac:.5f} of the samples agree"
 
 
+def test_scene_with_more_objects_than_the_on_chip_tables_hold(tmp_path, ob):
+    """150 objects do not fit the LDS copies of the scene tables: the scene is traced by the general kernels."""
+    from pathtracing_amd import scenes
+    rng = np.random.default_rng(3)
+    scene = scenes.cornell_example_dict()
+    materials = [m["name"] for m in scene["materials"]]
+    for k in range(138):
+        position = [float(rng.uniform(-0.8, 0.8)), float(rng.uniform(0.05, 1.5)), float(rng.uniform(-1.8, -0.2))]
+        scene["objects"].append(scenes._sphere(f"bead_{k}", position, float(rng.uniform(0.02, 0.06)), materials[k % len(materials)]))
+    d = scenes.write_scene_directory(str(tmp_path / "beads"), scene, scenes.default_settings(WIDTH=48, HEIGHT=36))
+    hs = pt.load_scene_directory(d)
+    n = hs.settings.width * hs.settings.height
+    job = pt.make_job(0, n, 4, 0, 9)
+    want = ob.OracleScene(hs).trace_samples(job)
+    for tail_records in (131072, 0):
+        pt.set_option("tail_records", tail_records)
+        try:
+            dev = pt.DeviceScene(hs)
+            assert dev.bounce_kernel().endswith("false>"), dev.bounce_kernel()
+            got = dev.trace_samples(job)
+        finally:
+            pt.set_option("tail_records", 131072)
+        for w, g, what in zip(want, got, ("radiance", "position", "normal")):
+            frac = _close_fraction(g.reshape(-1, 3), w.reshape(-1, 3))
+            assert frac >= 0.999, f"{what}: only {frac:.5f} of the samples agree"
+
+
 def test_degenerate_jobs_and_scenes(tmp_path, ob):
     from pathtracing_amd import scenes
     # a scene with no light and one with nothing but the background
