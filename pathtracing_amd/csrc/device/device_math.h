@@ -106,8 +106,11 @@ struct Rng {
 };
 
 // ---- src/utils.cpp ------------------------------------------------------------------------
+// fmod(x, 1.0) is x minus its integer part, exactly (the fractional part of a double is representable), so the two
+// fmod calls of the reference cost a truncation and a subtraction each instead of the general remainder routine.
 PTK_DEV double pos_fmod1(double a) { // pos_fmod(a, 1.0), :32-34
-    return fmod(fmod(a, 1.0) + 1.0, 1.0);
+    const double shifted = (a - trunc(a)) + 1.0;
+    return shifted - trunc(shifted);
 }
 
 PTK_DEV bool solve_quadratic(double b, double c, double& distance) { // :52-71
