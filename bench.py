@@ -89,6 +89,13 @@ def cpu_baseline(host_scene, args, threads):
     t0 = time.perf_counter()
     osc.render(job, image, pos, nrm, cnt, threads=threads)
     rate = rows * W / max(time.perf_counter() - t0, 1e-9)
+    # the thin slice underestimates the rate (thread start-up, one region of the frame): a whole frame at a sample
+    # count sized for about a second gives the figure the final sample is sized with
+    spp = int(max(1, min(64, rate * 1.0 / (W * H))))
+    job = pt.make_job(0, W * H, spp, 0, args.seed)
+    t0 = time.perf_counter()
+    osc.render(job, image, pos, nrm, cnt, threads=threads)
+    rate = max(rate, W * H * spp / max(time.perf_counter() - t0, 1e-9))
     budget = rate * 12.0  # paths
     spp = int(max(1, min(256, budget / (W * H))))
     n_pixels = W * H if budget >= W * H else int(max(W, budget // W * W))
