@@ -37,8 +37,11 @@ std::string bounce_kernel_name(const DevScene& sc);
 // false: every scene runs the general kernels (all features compiled in, tables read from memory) instead of the
 // ones specialised on its contents; the results are the same.
 void set_specialised_kernels(bool on);
-// Every remaining bounce of the paths in `list` (at most `bound` of them, bound <= TAIL_RECORDS) in one launch.
-constexpr uint32_t TAIL_RECORDS = 131072;
+// Every remaining bounce of the paths in `list` (at most `bound` of them) in one launch.  TAIL_RECORDS is the default
+// count at which a batch switches to it (scenes with meshes: twice that), measured on one MI355X: the bounces of
+// fewer than a million paths no longer fill the device, and three launches per bounce cost more than the sorting
+// they buy.
+constexpr uint32_t TAIL_RECORDS = 1u << 20;
 void launch_tail(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
                  const SampleResults& res, const uint32_t* list, const BinInfo* info, unsigned long long* statistics);
 // Scenes with meshes, after launch_bounce: the hierarchy walks of the queued rays (statistics slots: [0] rays,

@@ -26,6 +26,7 @@ thread_local std::string g_error;
 hipStream_t g_stream = nullptr;
 int g_device = -1;
 bool g_profiling = false;
+constexpr uint32_t TAIL_RECORDS_LIMIT = 1u << 24; // upper limit of the tail_records option (no batch is larger)
 uint32_t g_tail_records = TAIL_RECORDS;
 
 int fail(int code, const std::string& message) {
@@ -323,7 +324,8 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
         timer.begin(1);
         launch_bin(g_stream, s->dev, current, bound, pool_rounds, previous, s->block_counts, s->count_stride, info, s->list);
         timer.end();
-        if (bound <= g_tail_records) { // few paths left: one launch follows every one of them to its end
+        const uint64_t tail_at = s->dev.has_meshes ? 2ull * g_tail_records : g_tail_records;
+        if (bound <= tail_at) { // few paths left: one launch follows every one of them to its end
             timer.begin(0);
             launch_tail(g_stream, bound, s->dev, b, current, next, s->results, s->list, info, s->d_statistics);
             timer.end();
@@ -463,8 +465,8 @@ int ptk_init(int device) {
 
 int ptk_set_option(const char* name, int64_t value) {
     if (name && std::strcmp(name, "tail_records") == 0) {
-        if (value < 0 || value > static_cast<int64_t>(TAIL_RECORDS))
-            return fail(PTK_ERR_INVALID, "ptk_set_option: tail_records must be between 0 and 131072");
+        if (value < 0 || value > static_cast<int64_t>(TAIL_RECORDS_LIMIT))
+            return fail(PTK_ERR_INVALID, "ptk_set_option: tail_records must be between 0 and 16777216");
         g_tail_records = static_cast<uint32_t>(value);
         return PTK_OK;
     }

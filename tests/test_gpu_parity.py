@@ -48,7 +48,7 @@ def test_primary_hits_match_oracle(scene_dirs, ob, name):
 # tail_records: with the default the small test frames are traced by k_tail alone (one lane follows one
 # path to its end); 0 sends every bounce through the class sort and k_bounce (and, with meshes, the
 # deferral, k_traverse and k_bounce_resume); 1500 switches from the one to the other part-way.
-@pytest.mark.parametrize("tail_records", [131072, 0, 1500])
+@pytest.mark.parametrize("tail_records", [1048576, 0, 1500])
 @pytest.mark.parametrize("name", SCENES)
 def test_samples_match_oracle(scene_dirs, ob, name, tail_records):
     hs = pt.load_scene_directory(scene_dirs[name])
@@ -59,7 +59,7 @@ def test_samples_match_oracle(scene_dirs, ob, name, tail_records):
     try:
         got = pt.DeviceScene(hs).trace_samples(job)
     finally:
-        pt.set_option("tail_records", 131072)
+        pt.set_option("tail_records", 1048576)
     for w, g, what in zip(want, got, ("radiance", "position", "normal")):
         w2, g2 = w.reshape(-1, 3), g.reshape(-1, 3)
         frac = _close_fraction(g2, w2)
@@ -82,7 +82,7 @@ def test_results_do_not_depend_on_batch_size_or_knobs(scene_dirs, name):
         try:
             other = pt.DeviceScene(hs).trace_samples(job)
         finally:
-            pt.set_option("tail_records", 131072)
+            pt.set_option("tail_records", 1048576)
         for a, b in zip(whole, other):
             assert np.array_equal(a, b)
 
@@ -94,7 +94,7 @@ def test_general_kernels_give_the_same_results(scene_dirs, name):
     hs = pt.load_scene_directory(scene_dirs[name])
     n = hs.settings.width * hs.settings.height
     job = pt.make_job(0, n, 3, 0, 31)
-    for tail_records in (131072, 0):
+    for tail_records in (1048576, 0):
         pt.set_option("tail_records", tail_records)
         try:
             dev = pt.DeviceScene(hs)
@@ -105,7 +105,7 @@ def test_general_kernels_give_the_same_results(scene_dirs, name):
             general = dev.trace_samples(job)
         finally:
             pt.set_option("specialised_kernels", 1)
-            pt.set_option("tail_records", 131072)
+            pt.set_option("tail_records", 1048576)
         for a, b in zip(specialised, general):
             assert np.array_equal(a, b)
 
@@ -206,12 +206,12 @@ def test_settings_variations_match_oracle(scene_dirs, ob, name, overrides):
     n = hs.settings.width * hs.settings.height
     job = pt.make_job(0, n, 3, 1, 4242)
     want = ob.OracleScene(hs).trace_samples(job)
-    for tail_records in (131072, 0):
+    for tail_records in (1048576, 0):
         pt.set_option("tail_records", tail_records)
         try:
             got = pt.DeviceScene(hs).trace_samples(job)
         finally:
-            pt.set_option("tail_records", 131072)
+            pt.set_option("tail_records", 1048576)
         for w, g, what in zip(want, got, ("radiance", "position", "normal")):
             frac = _close_fraction(g.reshape(-1, 3), w.reshape(-1, 3))
             assert frac >= 0.999, f"{name} {overrides} {what}: only {frac:.5f} of the samples agree"
@@ -231,14 +231,14 @@ def test_scene_with_more_objects_than_the_on_chip_tables_hold(tmp_path, ob):
     n = hs.settings.width * hs.settings.height
     job = pt.make_job(0, n, 4, 0, 9)
     want = ob.OracleScene(hs).trace_samples(job)
-    for tail_records in (131072, 0):
+    for tail_records in (1048576, 0):
         pt.set_option("tail_records", tail_records)
         try:
             dev = pt.DeviceScene(hs)
             assert dev.bounce_kernel().endswith("false>"), dev.bounce_kernel()
             got = dev.trace_samples(job)
         finally:
-            pt.set_option("tail_records", 131072)
+            pt.set_option("tail_records", 1048576)
         for w, g, what in zip(want, got, ("radiance", "position", "normal")):
             frac = _close_fraction(g.reshape(-1, 3), w.reshape(-1, 3))
             assert frac >= 0.999, f"{what}: only {frac:.5f} of the samples agree"
