@@ -43,7 +43,7 @@ void set_specialised_kernels(bool on);
 // they buy.
 constexpr uint32_t TAIL_RECORDS = 1u << 20;
 void launch_tail(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
-                 const SampleResults& res, const uint32_t* list, const BinInfo* info, unsigned long long* statistics);
+                 const SampleResults& res, const uint32_t* list, BinInfo* info, unsigned long long* statistics);
 // Scenes with meshes, after launch_bounce: the hierarchy walks of the queued rays (statistics slots: [0] rays,
 // [1] nodes visited, [2] triangles tested), then the deferred vertices.
 void launch_traverse(hipStream_t s, uint32_t bound, const DevScene& sc, const DeferQueues& queues, unsigned long long* statistics);

@@ -68,7 +68,10 @@ __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* block_counts, uint3
             info->count[c] = carry - class_start;
         }
     }
-    if (threadIdx.x == 0) info->total = carry;
+    if (threadIdx.x == 0) {
+        info->total = carry;
+        info->cursor = 0;
+    }
 }
 
 // Writes the class-sorted index list: a record that continues with class c goes to
@@ -435,8 +438,9 @@ void launch_bounce(hipStream_t s, uint32_t bound, uint32_t rounds, const DevScen
 }
 
 void launch_tail(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
-                 const SampleResults& res, const uint32_t* list, const BinInfo* info, unsigned long long* statistics) {
-    const dim3 grid((bound + BLOCK - 1) / BLOCK + 1);
+                 const SampleResults& res, const uint32_t* list, BinInfo* info, unsigned long long* statistics) {
+    // at most one device fill (256 CUs, two blocks of four waves each at two waves per SIMD): the waves are persistent
+    const dim3 grid(min((bound + BLOCK - 1) / BLOCK + 1, 512u));
     Variant v = variant_of(sc);
     if (v.tris) v.pass = true;
 #define PTK_CASE(T, U, P, C)                                            \

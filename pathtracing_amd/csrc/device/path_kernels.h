@@ -804,6 +804,8 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
     }
 }
 
+constexpr uint32_t TAIL_REFILL_LANES = 16; // idle lanes at which a wave of k_tail fetches new paths
+
 // The last bounces of a batch, when few paths are left: one lane follows one path to its end,
 // without the class sort between bounces (the class switch is per lane here, which costs nothing
 // at this size), so the tail of the path-length distribution costs one launch instead of three per
@@ -812,24 +814,50 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
 template<bool TRIS, bool UV, bool PASS, bool CACHE>
 __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES : PTK_BOUNCE_WAVES) void k_tail(DevScene sc_global, BatchParams b, PathPool in, PathPool out,
                                                                                     SampleResults res, const uint32_t* list,
-                                                                                    const BinInfo* info, unsigned long long* statistics) {
+                                                                                    BinInfo* info, unsigned long long* statistics) {
     __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1];
     __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
     PTK_TRAVERSAL_STACK(st, lds_stack);
     const uint32_t n = info->total;
-    if (blockIdx.x * BLOCK >= n) return;
     __shared__ double lds_scene[CACHE ? LDS_SCENE_DOUBLES : 1];
     const DevScene sc = stage_scene<CACHE>(sc_global, lds_scene);
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     uint32_t stat[N_STATISTICS] = {};
-    if (i < n) {
-        const uint32_t first_src = list[i];
-        int cls = in.cls[first_src];
-        for (int round = 0; cls >= 0; round++) {
-            const Record cur = round == 0 ? load_record(in, first_src) : load_record(out, i);
+    // Path lengths are geometric (Russian roulette): a wave that kept its 64 paths until the longest ended would run
+    // three quarters empty.  Lanes whose path has ended take the next one from the list once 16 of them are idle
+    // (info->cursor, zeroed by k_bin_scan); the grid fills the device once and every wave leaves when the list is
+    // handed out and its own paths have ended.
+    bool exhausted = false; // wave-uniform
+    uint32_t i = 0, first_src = 0;
+    int cls = -1;           // -1: the lane has no path
+    bool fresh = false;     // the path's record is still the one of the input pool
+    for (;;) {
+        const unsigned long long idle = __ballot(cls < 0);
+        const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle));
+        if (!exhausted && n_idle >= TAIL_REFILL_LANES) {
+            uint32_t base = 0;
+            if (cls < 0 && lanes_below(idle) == 0) base = atomicAdd(&info->cursor, n_idle); // the first idle lane
+            base = __shfl(base, __ffsll(static_cast<long long>(idle)) - 1);
+            if (cls < 0) {
+                const uint32_t mine = base + lanes_below(idle);
+                if (mine < n) {
+                    i = mine;
+                    first_src = list[i];
+                    cls = in.cls[first_src];
+                    fresh = true;
+                }
+            }
+            exhausted = base + n_idle >= n;
+        }
+        if (__ballot(cls >= 0) == 0) {
+            if (exhausted) break;
+            continue; // all 64 lanes are idle: the next pass fetches
+        }
+        if (cls >= 0) {
+            const Record cur = fresh ? load_record(in, first_src) : load_record(out, i);
             PathVertex v;
             const bool alive = shade_record<TRIS, UV>(sc, b, res, cur, cls, v);
-            if (round > 0) stat[4]++;
+            if (!fresh) stat[4]++;
+            fresh = false;
             double scatter_distance = INF;
             if (alive) scatter_distance = free_flight_distance(sc, b, medium_bits_of(v), v.sid, v.rng.ctr);
             RayState rays[2];

@@ -253,7 +253,8 @@ struct BinInfo {
     uint32_t start[N_CLASSES]; // first entry of each class segment in the sorted list
     uint32_t count[N_CLASSES];
     uint32_t total;            // length of the sorted list = records the bounce writes to the other pool
-    uint32_t _pad[15];
+    uint32_t cursor;           // next list entry k_tail hands out (k_bin_scan leaves it at zero)
+    uint32_t _pad[14];
 };
 
 } // namespace ptk

@@ -22,7 +22,7 @@ void launch_bounce_variant(hipStream_t s, dim3 grid, const DevScene& sc, const B
 
 template<bool TRIS, bool UV, bool PASS, bool CACHE>
 void launch_tail_variant(hipStream_t s, dim3 grid, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
-                         const SampleResults& res, const uint32_t* list, const BinInfo* info, unsigned long long* statistics);
+                         const SampleResults& res, const uint32_t* list, BinInfo* info, unsigned long long* statistics);
 
 template<bool UV, bool PASS, bool CACHE>
 void launch_resume_variant(hipStream_t s, dim3 grid, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,

@@ -16,7 +16,7 @@
 #define PTK_TAIL_VARIANT(T, U, P, C)                                                                                                   \
     template<>                                                                                                                         \
     void launch_tail_variant<T, U, P, C>(hipStream_t s, dim3 grid, const DevScene& sc, const BatchParams& b, const PathPool& in,       \
-                                         const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info,     \
+                                         const PathPool& out, const SampleResults& res, const uint32_t* list, BinInfo* info,           \
                                          unsigned long long* statistics) {                                                             \
         hipLaunchKernelGGL((k_tail<T, U, P, C>), grid, dim3(BLOCK), 0, s, sc, b, in, out, res, list, info, statistics);                \
     }
