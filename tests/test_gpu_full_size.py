@@ -52,6 +52,15 @@ def test_frame_is_the_same_however_it_is_cut(which, example, mesh):
     cut = N // 3 + 17
     pieces, _ = render(hs, [pt.make_job(0, cut, SPP, 0, 11), pt.make_job(cut, N - cut, SPP, 0, 11)], max_paths_in_flight=3_000_000)
     assert all(np.array_equal(a, b) for a, b in zip(whole, pieces))
+    # every bounce through the class sort and k_bounce (0), or the whole frame through the persistent k_tail (2^24):
+    # bit-identical to the default, which switches from the one to the other part-way
+    for tail_records in (0, 1 << 24):
+        pt.set_option("tail_records", tail_records)
+        try:
+            other, _ = render(hs, [pt.make_job(0, N, SPP, 0, 11)])
+        finally:
+            pt.set_option("tail_records", 1 << 20)
+        assert all(np.array_equal(a, b) for a, b in zip(whole, other)), tail_records
     # sample slices folded one after the other (what two GPUs would add up): equal up to rounding of the mean
     slices, _ = render(hs, [pt.make_job(0, N, SPP // 2, 0, 11), pt.make_job(0, N, SPP - SPP // 2, SPP // 2, 11)])
     np.testing.assert_allclose(slices[0], image, rtol=1e-12, atol=1e-15)
