@@ -235,9 +235,25 @@ def main():
                 traffic = json.load(f).get(args.workload, {}).get(kernel)
         except Exception:
             traffic = None
+    # SQ counters of the same kernel from the last rocprofv3 --pmc passes kept under profiles/ (tools/counters_digest.py):
+    # the share of the SIMDs' issue slots spent on vector instructions and the occupancy the kernel is compiled for
+    valu = None
+    counters_file = os.path.join(ROOT, "profiles", "counters_latest.json")
+    if os.path.exists(counters_file):
+        try:
+            with open(counters_file) as f:
+                c = json.load(f).get(args.workload, {}).get(kernel)
+            if c and "valu_share_of_wave_time" in c:
+                waves_per_simd = 5 if kernel == "ptk::k_traverse" else 2
+                valu = {"waves_per_simd": waves_per_simd, "occupancy_frac_of_8": waves_per_simd / 8.0,
+                        "simd_issue_busy": c["valu_share_of_wave_time"] * waves_per_simd,
+                        "active_lanes_per_instruction": c.get("active_lanes_per_valu"),
+                        "valu_instructions_per_wave": c.get("valu_per_wave"), "source": "profiles/counters_latest.json"}
+        except Exception:
+            valu = None
     vertices_by_class = {CLASS_NAMES[c]: int(st.class_vertices[c]) for c in range(8) if st.class_vertices[c]}
     roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu": valu,
                 "bytes_per_launch": d_bytes / max(d_launches, 1), "ms_per_launch": d_ms / max(d_launches, 1),
                 "launches": int(d_launches), "profiled_steps": profiled["steps"],
                 "device_ms": {"k_bounce": fam["k_bounce"][0], "k_bin": fam["k_bin"][0], "k_traverse": fam["k_traverse"][0],

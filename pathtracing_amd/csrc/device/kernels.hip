@@ -388,6 +388,10 @@ void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_
 
 // ---- choice of kernel variant (see variants.h) ---------------------------------------------------
 static bool g_specialised = true;
+static uint32_t g_compute_units = 256; // of the device in use: sizes the grids of the persistent kernels
+void set_compute_units(int n) {
+    if (n > 0) g_compute_units = static_cast<uint32_t>(n);
+}
 void set_specialised_kernels(bool on) {
     g_specialised = on;
 }
@@ -439,8 +443,8 @@ void launch_bounce(hipStream_t s, uint32_t bound, uint32_t rounds, const DevScen
 
 void launch_tail(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
                  const SampleResults& res, const uint32_t* list, BinInfo* info, unsigned long long* statistics) {
-    // at most one device fill (256 CUs, two blocks of four waves each at two waves per SIMD): the waves are persistent
-    const dim3 grid(min((bound + BLOCK - 1) / BLOCK + 1, 512u));
+    // at most one device fill (two blocks of four waves per CU at two waves per SIMD): the waves are persistent
+    const dim3 grid(min((bound + BLOCK - 1) / BLOCK + 1, 2u * g_compute_units));
     Variant v = variant_of(sc);
     if (v.tris) v.pass = true;
 #define PTK_CASE(T, U, P, C)                                            \
@@ -457,8 +461,8 @@ void launch_tail(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchP
 }
 
 void launch_traverse(hipStream_t s, uint32_t bound, const DevScene& sc, const DeferQueues& queues, unsigned long long* statistics) {
-    // enough blocks to fill the device once (256 CUs, PTK_TRAVERSE_WAVES waves per SIMD, four waves per block)
-    const uint32_t resident = 256u * PTK_TRAVERSE_WAVES;
+    // enough blocks to fill the device once (PTK_TRAVERSE_WAVES waves per SIMD, four SIMDs per CU, four waves per block)
+    const uint32_t resident = g_compute_units * PTK_TRAVERSE_WAVES;
     const dim3 grid(min((2 * bound + BLOCK - 1) / BLOCK + 1, resident));
     hipLaunchKernelGGL(k_traverse, grid, dim3(BLOCK), 0, s, sc, queues, statistics);
 }

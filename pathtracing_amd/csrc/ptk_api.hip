@@ -452,6 +452,7 @@ int ptk_init(int device) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(PTK_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", but the kernels are built for gfx950 only");
+    set_compute_units(prop.multiProcessorCount);
     if (g_stream && g_device != device) {
         (void) hipStreamDestroy(g_stream);
         g_stream = nullptr;
