@@ -759,6 +759,19 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     dev.n_maps = d->n_maps;
     dev.n_lights = static_cast<int32_t>(lights.size());
     dev.has_triangles = !tri_hot.empty();
+    // Material::allow_direct_light (src/materials.cpp:55-60, :129-136) can only say yes through a transparency above
+    // zero somewhere in the material's transparency map, or for a Transparent material between media of equal
+    // refractive index.
+    auto lets_light_through = [&](const DevMaterial& m) {
+        double most = 0;
+        if (m.transparency >= 0) {
+            const PtkMap& map = d->maps[m.transparency];
+            const int64_t texels = static_cast<int64_t>(map.width) * map.height;
+            for (int64_t k = 0; k < texels; k++) most = std::max(most, d->map_data[map.offset + k]);
+        }
+        auto ior = [&](int medium) { return medium >= 0 ? media[static_cast<size_t>(medium)].ior : 1.0; };
+        return most > 0 || (m.type == PTK_MAT_TRANSPARENT && ior(m.internal_medium) == ior(m.external_medium));
+    };
     std::vector<DevShape> shapes(objects.size());
     for (size_t i = 0; i < objects.size(); i++) {
         const DevObject& o = objects[i];
@@ -794,10 +807,7 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
             // transparency above zero or a Transparent material between media of equal refractive index;
             // a light has to be found exactly (its distance is compared with the sampled point's).
             const DevMaterial& m = o.mat;
-            auto ior = [&](int medium) { return medium >= 0 ? media[static_cast<size_t>(medium)].ior : 1.0; };
-            const bool passes = m.needs_uv || m.c_transparency > 0 ||
-                                (m.type == PTK_MAT_TRANSPARENT && ior(m.internal_medium) == ior(m.external_medium));
-            sh.f[6] = (!passes && !m.is_light) ? 1.0 : 0.0;
+            sh.f[6] = (!lets_light_through(m) && !m.is_light) ? 1.0 : 0.0;
         }
         else if (o.type == PTK_OBJ_PLANE || o.type == PTK_OBJ_RECTANGLE) {
             const double v[14] = {o.px, o.py, o.pz, o.nx, o.ny, o.nz, o.v1x, o.v1y, o.v1z, o.v2x, o.v2y, o.v2z, o.L1, o.L2};
@@ -813,12 +823,8 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     dev.has_pass_through = 0;
     dev.tables_fit_lds = (objects.size() + lights.size()) * sizeof(DevObject) + media.size() * sizeof(DevMedium) <=
                          static_cast<size_t>(LDS_SCENE_DOUBLES) * sizeof(double);
-    for (const DevMaterial& m : materials) {
-        // Material::allow_direct_light (src/materials.cpp:55-60, :129-136)
-        auto ior = [&](int medium) { return medium >= 0 ? media[static_cast<size_t>(medium)].ior : 1.0; };
-        if (m.needs_uv || m.c_transparency > 0 || (m.type == PTK_MAT_TRANSPARENT && ior(m.internal_medium) == ior(m.external_medium)))
-            dev.has_pass_through = 1;
-    }
+    for (const DevMaterial& m : materials)
+        if (lets_light_through(m)) dev.has_pass_through = 1;
     for (const DevMaterial& m : materials)
         if (m.needs_uv) dev.needs_uv = 1;
     for (const DevObject& o : objects)
