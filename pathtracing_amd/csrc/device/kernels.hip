@@ -172,7 +172,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_WAVES) void 
                     const V3 dir = v3(q.dx, q.dy, q.dz);
                     rp = prepare_ray(dir);
                     slab = slab_ray(org, dir, sc.mesh_bound_abs);
-                    best = RayResult{q.limit, -1, 0};
+                    best = RayResult{q.limit, static_cast<int32_t>(q.object), 0}; // the closest hit among the other objects
                     slot = q.slot;
                     mesh = -1;
                     node = BVH_EMPTY;

@@ -785,9 +785,9 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
                         if (rays[k].needs_mesh) {
                             // t_max is the closest hit among the other objects: the walk starts culled
                             queues.rays[ray_slot++] = RayRequest{origin.x, origin.y, origin.z, rays[k].dir.x, rays[k].dir.y, rays[k].dir.z,
-                                                                 rays[k].limit, 2 * dst + k, 0u};
+                                                                 rays[k].limit, 2 * dst + k, static_cast<uint32_t>(rays[k].obj)};
                         }
-                        else queues.results[2 * dst + k] = RayResult{INF, -1, 0};
+                        else queues.results[2 * dst + k] = RayResult{rays[k].limit, rays[k].obj, rays[k].prim}; // what the scan found
                     }
                 }
                 __syncthreads(); // queue_counts and queue_base are rewritten next round
@@ -871,8 +871,8 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
 }
 
 // Finishes the deferred vertices: shades them again from the same records (same random numbers, so
-// the same two rays), scans the objects other than meshes, takes the closer of that hit and the
-// triangle k_traverse found, and goes on as k_bounce does.  The class counts go to the chunk the
+// the same two rays), takes the closest hits from the results (k_bounce's object scan, overridden by
+// k_traverse where a triangle is closer), and goes on as k_bounce does.  The class counts go to the chunk the
 // vertex came from, by atomics (they are spread over as many addresses as there are chunks).
 template<bool UV, bool PASS, bool CACHE>
 __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES : PTK_BOUNCE_WAVES) void k_bounce_resume(DevScene sc_global, BatchParams b, PathPool in,
@@ -895,19 +895,24 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
         const bool alive = shade_record<true, UV>(sc, b, res, cur, static_cast<int>(e.cls), v);
         double scatter_distance = INF;
         if (alive) scatter_distance = free_flight_distance(sc, b, medium_bits_of(v), v.sid, v.rng.ctr);
-        RayState rays[2];
-        vertex_rays<true>(v, alive, scatter_distance, rays);
-        scan_objects<true, MESH_SKIP, 2>(sc, v.point, rays, st);
+        // The closest hits of the two rays are in the results: what k_bounce's object scan found, replaced by
+        // k_traverse where a triangle of a mesh is closer (it starts from the scan's distance and object).
+        HitInfo hits[2];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const RayResult found = queues.results[2 * e.dst + k];
-            if (found.obj >= 0 && found.t < rays[k].limit) {
-                rays[k].limit = found.t;
-                rays[k].obj = found.obj;
-                rays[k].prim = found.prim;
+            no_hit(hits[k]);
+            if (found.obj >= 0) {
+                const DevObject& o = sc.objects[found.obj];
+                hits[k].t = found.t;
+                hits[k].obj = found.obj;
+                // a ray that went through k_traverse without finding a closer triangle carries no triangle index:
+                // the object is then not a mesh, and a single triangle's index is its object's first_tri
+                hits[k].prim = o.type == PTK_OBJ_MESH ? found.prim : (o.type == PTK_OBJ_TRIANGLE ? static_cast<int>(o.first_tri) : 0);
+                hits[k].cls = o.mat.type;
             }
         }
-        const int new_cls = finish_vertex<true, UV, PASS>(sc, out, res, e.dst, v, alive, scatter_distance, hit_of(sc, rays[0]), hit_of(sc, rays[1]), st, stat);
+        const int new_cls = finish_vertex<true, UV, PASS>(sc, out, res, e.dst, v, alive, scatter_distance, hits[0], hits[1], st, stat);
         if (new_cls >= 0) atomicAdd(block_counts + static_cast<size_t>(new_cls) * count_stride + e.chunk, 1u);
     }
     add_block_statistics(statistics, wave_sums, stat);

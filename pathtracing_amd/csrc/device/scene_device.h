@@ -201,13 +201,13 @@ struct PathPool {
 // record, same random numbers, hence the same rays) and finishes them with the traversal results.
 struct RayRequest { // 64 bytes
     double ox, oy, oz, dx, dy, dz;
-    double limit;   // t_max
-    uint32_t slot;  // 2 * record position in the output pool + (0 shadow ray, 1 extension ray)
-    uint32_t _pad;
+    double limit;    // t_max: the distance of the closest hit among the objects that are not meshes
+    uint32_t slot;   // 2 * record position in the output pool + (0 shadow ray, 1 extension ray)
+    uint32_t object; // that hit's object, 0xFFFFFFFF (-1) if none
 };
-struct RayResult { // 16 bytes; obj < 0: no triangle closer than the limit
+struct RayResult { // 16 bytes: the closest hit of a deferred vertex's ray; obj < 0: none
     double t;
-    int32_t obj, prim;
+    int32_t obj, prim; // prim: the triangle when obj is a mesh
 };
 struct DeferredVertex { // 16 bytes
     uint32_t dst, src; // record positions in the output and input pools
