@@ -873,7 +873,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
 // Finishes the deferred vertices: shades them again from the same records (same random numbers, so
 // the same two rays), takes the closest hits from the results (k_bounce's object scan, overridden by
 // k_traverse where a triangle is closer), and goes on as k_bounce does.  The class counts go to the chunk the
-// vertex came from, by atomics (they are spread over as many addresses as there are chunks).
+// vertex came from, by atomics (one per wave and distinct chunk).
 template<bool UV, bool PASS, bool CACHE>
 __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES : PTK_BOUNCE_WAVES) void k_bounce_resume(DevScene sc_global, BatchParams b, PathPool in,
                                                                                              PathPool out, SampleResults res,
@@ -888,11 +888,32 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
     __shared__ double lds_scene[CACHE ? LDS_SCENE_DOUBLES : 1];
     const DevScene sc = stage_scene<CACHE>(sc_global, lds_scene);
     uint32_t stat[N_STATISTICS] = {};
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
-        const DeferredVertex e = queues.vertices[i];
-        const Record cur = load_record(in, e.src);
+    // Software pipeline over the vertices of a lane, as in k_bounce: the next vertex's record and results are
+    // requested in the middle of the current one, its queue entry one step earlier still.
+    const uint32_t stride = gridDim.x * BLOCK;
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    DeferredVertex e{}, e_next{};
+    Record cur{};
+    RayResult found[2] = {};
+    if (i < n) {
+        e = queues.vertices[i];
+        cur = load_record(in, e.src);
+        found[0] = queues.results[2 * e.dst];
+        found[1] = queues.results[2 * e.dst + 1];
+    }
+    if (i + stride < n) e_next = queues.vertices[i + stride];
+    for (; i < n; i += stride) {
         PathVertex v;
         const bool alive = shade_record<true, UV>(sc, b, res, cur, static_cast<int>(e.cls), v);
+        Record nxt{};
+        RayResult found_next[2] = {};
+        DeferredVertex e_after{};
+        if (i + stride < n) {
+            nxt = load_record(in, e_next.src);
+            found_next[0] = queues.results[2 * e_next.dst];
+            found_next[1] = queues.results[2 * e_next.dst + 1];
+        }
+        if (i + 2 * stride < n) e_after = queues.vertices[i + 2 * stride];
         double scatter_distance = INF;
         if (alive) scatter_distance = free_flight_distance(sc, b, medium_bits_of(v), v.sid, v.rng.ctr);
         // The closest hits of the two rays are in the results: what k_bounce's object scan found, replaced by
@@ -900,20 +921,34 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
         HitInfo hits[2];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            const RayResult found = queues.results[2 * e.dst + k];
             no_hit(hits[k]);
-            if (found.obj >= 0) {
-                const DevObject& o = sc.objects[found.obj];
-                hits[k].t = found.t;
-                hits[k].obj = found.obj;
+            if (found[k].obj >= 0) {
+                const DevObject& o = sc.objects[found[k].obj];
+                hits[k].t = found[k].t;
+                hits[k].obj = found[k].obj;
                 // a ray that went through k_traverse without finding a closer triangle carries no triangle index:
                 // the object is then not a mesh, and a single triangle's index is its object's first_tri
-                hits[k].prim = o.type == PTK_OBJ_MESH ? found.prim : (o.type == PTK_OBJ_TRIANGLE ? static_cast<int>(o.first_tri) : 0);
+                hits[k].prim = o.type == PTK_OBJ_MESH ? found[k].prim : (o.type == PTK_OBJ_TRIANGLE ? static_cast<int>(o.first_tri) : 0);
                 hits[k].cls = o.mat.type;
             }
         }
         const int new_cls = finish_vertex<true, UV, PASS>(sc, out, res, e.dst, v, alive, scatter_distance, hits[0], hits[1], st, stat);
-        if (new_cls >= 0) atomicAdd(block_counts + static_cast<size_t>(new_cls) * count_stride + e.chunk, 1u);
+        // One atomic per distinct (class, chunk) among the lanes of the wave: neighbouring lanes mostly hold vertices
+        // of one chunk, and one atomic per lane made this kernel wait for the atomic unit of the L2.
+        uint32_t key = new_cls >= 0 ? static_cast<uint32_t>(new_cls) * count_stride + e.chunk : 0xFFFFFFFFu;
+        while (key != 0xFFFFFFFFu) {
+            const uint32_t first_key = __builtin_amdgcn_readfirstlane(key);
+            const unsigned long long same = __ballot(key == first_key);
+            if (key == first_key) {
+                if (lanes_below(same) == 0) atomicAdd(block_counts + first_key, static_cast<uint32_t>(__popcll(same)));
+                key = 0xFFFFFFFFu;
+            }
+        }
+        e = e_next;
+        e_next = e_after;
+        cur = nxt;
+        found[0] = found_next[0];
+        found[1] = found_next[1];
     }
     add_block_statistics(statistics, wave_sums, stat);
 }
