@@ -40,7 +40,7 @@ void set_specialised_kernels(bool on);
 // number of compute units of the device in use (sizes the grids of the persistent kernels; 256 until told otherwise)
 void set_compute_units(int n);
 // Every remaining bounce of the paths in `list` (at most `bound` of them) in one launch.  TAIL_RECORDS is the default
-// count at which a batch switches to it (scenes with meshes: twice that), measured on one MI355X: the bounces of
+// count at which a batch switches to it (scenes with meshes: four times that), measured on one MI355X: the bounces of
 // fewer than a million paths no longer fill the device, and three launches per bounce cost more than the sorting
 // they buy.
 constexpr uint32_t TAIL_RECORDS = 1u << 20;

@@ -324,7 +324,7 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
         timer.begin(1);
         launch_bin(g_stream, s->dev, current, bound, pool_rounds, previous, s->block_counts, s->count_stride, info, s->list);
         timer.end();
-        const uint64_t tail_at = s->dev.has_meshes ? 2ull * g_tail_records : g_tail_records;
+        const uint64_t tail_at = s->dev.has_meshes ? 4ull * g_tail_records : g_tail_records;
         if (bound <= tail_at) { // few paths left: one launch follows every one of them to its end
             timer.begin(0);
             launch_tail(g_stream, bound, s->dev, b, current, next, s->results, s->list, info, s->d_statistics);
