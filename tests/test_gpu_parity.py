@@ -244,6 +244,40 @@ def test_scene_with_more_objects_than_the_on_chip_tables_hold(tmp_path, ob):
             assert frac >= 0.999, f"{what}: only {frac:.5f} of the samples agree"
 
 
+def test_scene_with_more_meshes_than_the_traversal_kernel_keeps_on_chip(tmp_path, ob):
+    """270 small meshes: the list of meshes is read from memory by k_traverse, and the general kernels shade."""
+    import os
+    from pathtracing_amd import scenes
+    rng = np.random.default_rng(5)
+    d = str(tmp_path / "swarm")
+    scenes.write_bumpy_sphere_obj(os.path.join(d, "models", "pebble.obj"), 8, 5, seed=3, bump=0.15)
+    scene = scenes.cornell_example_dict()
+    materials = ["red_diffuse_material", "gold_material", "white_diffuse_material", "blue_diffuse_material"]
+    for k in range(270):
+        center = [float(rng.uniform(-0.8, 0.8)), float(rng.uniform(0.1, 1.6)), float(rng.uniform(-1.8, -0.2))]
+        scene["objects"].append({"name": f"pebble_{k}", "type": "Object", "subtype": "ObjectUnion",
+                                 "parameters": {"file": "models/pebble.obj", "material": materials[k % 4],
+                                                "enable_smooth_shading": bool(k & 1), "center": center,
+                                                "size": float(rng.uniform(0.04, 0.09)),
+                                                "orientation": {"X": float(rng.uniform(0, 90)), "Y": 0.0, "Z": 0.0}}})
+    scenes.write_scene_directory(d, scene, scenes.default_settings(WIDTH=40, HEIGHT=30))
+    hs = pt.load_scene_directory(d)
+    n = hs.settings.width * hs.settings.height
+    job = pt.make_job(0, n, 3, 0, 21)
+    want = ob.OracleScene(hs).trace_samples(job)
+    for tail_records in (1048576, 0):
+        pt.set_option("tail_records", tail_records)
+        try:
+            dev = pt.DeviceScene(hs)
+            assert dev.bounce_kernel().endswith("false>"), dev.bounce_kernel()
+            got = dev.trace_samples(job)
+        finally:
+            pt.set_option("tail_records", 1048576)
+        for w, g, what in zip(want, got, ("radiance", "position", "normal")):
+            frac = _close_fraction(g.reshape(-1, 3), w.reshape(-1, 3))
+            assert frac >= 0.999, f"{what}: only {frac:.5f} of the samples agree"
+
+
 def test_degenerate_jobs_and_scenes(tmp_path, ob):
     from pathtracing_amd import scenes
     # a scene with no light and one with nothing but the background
