@@ -255,7 +255,8 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(BatchParams b, SampleResul
             const size_t sid = static_cast<size_t>(s) * b.n_pixels + p;
             const double2* c = reinterpret_cast<const double2*>(res.color) + 2 * sid;
             const double2 ca = c[0], cb = c[1];
-            const double2 s0 = surface_plane(res, 0)[sid], s1 = surface_plane(res, 1)[sid], s2 = surface_plane(res, 2)[sid];
+            double2 s0, s1, s2;
+            load_surface(res, sid, cb, s0, s1, s2);
             sum[0] += ca.x;
             sum[1] += ca.y;
             sum[2] += cb.x;
@@ -291,7 +292,8 @@ __global__ __launch_bounds__(BLOCK) void k_gather_samples(BatchParams b, SampleR
             color[o + 1] = ca.y;
             color[o + 2] = cb.x;
         }
-        const double2 s0 = surface_plane(res, 0)[sid], s1 = surface_plane(res, 1)[sid], s2 = surface_plane(res, 2)[sid];
+        double2 s0, s1, s2;
+        load_surface(res, sid, reinterpret_cast<const double2*>(res.color)[2 * static_cast<size_t>(sid) + 1], s0, s1, s2);
         if (position) {
             position[o] = s0.x;
             position[o + 1] = s0.y;

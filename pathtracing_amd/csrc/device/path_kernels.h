@@ -132,13 +132,25 @@ PTK_DEV void stu4(const PathPool& p, int plane, uint32_t i, uint32_t a, uint32_t
 }
 
 // The path ended: its radiance goes to the per-sample results.
-PTK_DEV void flush_color(const SampleResults& res, uint32_t sid, double r, double g, double bl) {
+// has_surface: the path shaded a surface, so its first-surface position and normal are in the `surface` planes;
+// for the other paths those planes hold stale values that the readers replace by zeros.
+PTK_DEV void flush_color(const SampleResults& res, uint32_t sid, double r, double g, double bl, bool has_surface) {
     double2* c = reinterpret_cast<double2*>(res.color) + 2 * static_cast<size_t>(sid);
     c[0] = make_double2(r, g);
-    c[1] = make_double2(bl, 0.0);
+    c[1] = make_double2(bl, has_surface ? 1.0 : 0.0);
 }
+// first-surface position and normal of a sample whose radiance element is (ca, cb): planes (px, py), (pz, nx), (ny, nz)
+PTK_DEV void load_surface(const SampleResults& res, size_t sid, const double2& cb, double2& s0, double2& s1, double2& s2);
 PTK_DEV double2* surface_plane(const SampleResults& res, int plane) {
     return reinterpret_cast<double2*>(res.surface + static_cast<uint64_t>(plane) * res.plane_doubles);
+}
+PTK_DEV void load_surface(const SampleResults& res, size_t sid, const double2& cb, double2& s0, double2& s1, double2& s2) {
+    s0 = s1 = s2 = make_double2(0.0, 0.0);
+    if (cb.y != 0.0) {
+        s0 = surface_plane(res, 0)[sid];
+        s1 = surface_plane(res, 1)[sid];
+        s2 = surface_plane(res, 2)[sid];
+    }
 }
 
 // Statistics without atomics on shared lines: every block adds its totals to its own slot.
@@ -290,14 +302,11 @@ __global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, 
                 Rng rng{rng_key(b.seed, pixel, sample), 0};
                 V3 org, dir;
                 camera_ray(sc, pixel, rng, org, dir);
-                surface_plane(res, 0)[sid] = make_double2(0.0, 0.0);
-                surface_plane(res, 1)[sid] = make_double2(0.0, 0.0);
-                surface_plane(res, 2)[sid] = make_double2(0.0, 0.0);
                 const uint32_t medium = static_cast<uint32_t>(sc.background_medium) & 0xFFFFu;
                 const Vertex v = next_vertex<TRIS>(sc, b, org, dir, medium, sid, rng.ctr, st);
                 cls = v.cls;
                 if (v.cls < 0) { // color = throughput (1) * background_color
-                    flush_color(res, sid, sc.background[0], sc.background[1], sc.background[2]);
+                    flush_color(res, sid, sc.background[0], sc.background[1], sc.background[2], false);
                     pool.cls[sid] = CLASS_DONE;
                 }
                 else {
@@ -606,7 +615,7 @@ PTK_DEV int finish_vertex(const DevScene& sc, const PathPool& out, const SampleR
         if (nv.cls < 0 && !sc.background_is_black) v.color = v.color + v.thr * v3(sc.background);
     }
     if (nv.cls < 0) { // the path ended here
-        flush_color(res, v.sid, v.color.x, v.color.y, v.color.z);
+        flush_color(res, v.sid, v.color.x, v.color.y, v.color.z, v.has_hit);
         out.cls[dst] = CLASS_DONE;
         return -1;
     }

@@ -224,8 +224,8 @@ struct DeferQueues {
 // Per-sample results (PixelData, app/pathtracer.cpp:20-24), indexed by the sample's batch index
 // sid = sample * pixels_in_batch + pixel, so neighbouring lanes hold neighbouring pixels.
 struct SampleResults {
-    double* color;          // [n][4]: r, g, b, unused; written once, when the path ends
-    double* surface;        // 3 planes of [n][2]: (px, py), (pz, nx), (ny, nz) of the first surface hit
+    double* color;          // [n][4]: r, g, b, 1.0 if the path shaded a surface (else 0.0); written once, when the path ends
+    double* surface;        // 3 planes of [n][2]: (px, py), (pz, nx), (ny, nz) of the first surface hit (valid if color[.][3] != 0)
     uint64_t plane_doubles; // doubles per plane of `surface`
 };
 constexpr uint32_t DEPTH_MASK = 0x1FFFu;

@@ -220,7 +220,7 @@ constexpr uint64_t BOUNCE_BYTES_PER_ENDED = 32 + 1;                 // radiance 
 constexpr uint64_t BOUNCE_BYTES_PER_PATH = 3 * 16;                  // first-surface position and normal, once
 constexpr uint64_t BIN_BYTES_PER_RECORD = 1;                        // class in
 constexpr uint64_t BIN_BYTES_PER_VERTEX = 4;                        // list entry out
-constexpr uint64_t GENERATE_BYTES_PER_PATH = RECORD_BYTES + 1 + 3 * 16; // record, class, zeroed surface results out
+constexpr uint64_t GENERATE_BYTES_PER_PATH = RECORD_BYTES + 1;          // record, class out
 constexpr uint64_t ACCUMULATE_BYTES_PER_PATH = 32 + 3 * 16;         // results in
 constexpr uint64_t TRAVERSE_BYTES_PER_RAY = sizeof(RayRequest) + sizeof(RayResult);
 // two sets of statistics slots (k_bounce and k_bounce_resume; k_traverse), then their totals
