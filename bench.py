@@ -191,6 +191,12 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    if distributed and args.warmup > 0:
+        # the warm-up also runs the combine once: RCCL sets up its channels and torch's allocator gets its
+        # blocks at the first large collective, which would otherwise fall inside the timed region
+        pt.sync()
+        combine_films(t_img, t_pos, t_nrm, t_cnt)
+        torch.cuda.synchronize()
     barrier()
     film.clear()
     scene.reset_stats()
