@@ -30,6 +30,19 @@ def mesh(tmp_path_factory):
     return pt.load_scene_directory(d)
 
 
+@pytest.fixture(scope="module")
+def cloud(tmp_path_factory):
+    d = scenes.cloud_box(str(tmp_path_factory.mktemp("full_cloud")), WIDTH=W, HEIGHT=H)  # scattering medium + coloured glass
+    return pt.load_scene_directory(d)
+
+
+@pytest.fixture(scope="module")
+def room(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("full_room"))
+    scenes.living_room(d, mesh_lon=128, mesh_lat=65, texture_size=512, WIDTH=W, HEIGHT=H)  # 23 objects, 5 textured meshes
+    return pt.load_scene_directory(d)
+
+
 def render(host_scene, jobs, **kwargs):
     dev = pt.DeviceScene(host_scene, **kwargs)
     film = pt.Film(W, H)
@@ -38,9 +51,9 @@ def render(host_scene, jobs, **kwargs):
     return film.download(), dev.stats()
 
 
-@pytest.mark.parametrize("which", ["example", "mesh"])
-def test_frame_is_the_same_however_it_is_cut(which, example, mesh):
-    hs = example if which == "example" else mesh
+@pytest.mark.parametrize("which", ["example", "mesh", "cloud", "room"])
+def test_frame_is_the_same_however_it_is_cut(which, request):
+    hs = request.getfixturevalue(which)
     whole, stats = render(hs, [pt.make_job(0, N, SPP, 0, 11)])
     image, position, normal, counters = whole
     assert np.isfinite(image).all() and (image >= 0).all() and (counters == SPP).all()
@@ -68,10 +81,10 @@ def test_frame_is_the_same_however_it_is_cut(which, example, mesh):
     assert np.array_equal(slices[3], counters)
 
 
-@pytest.mark.parametrize("which", ["example", "mesh"])
-def test_scattered_pixel_runs_match_the_oracle(which, example, mesh):
+@pytest.mark.parametrize("which", ["example", "mesh", "cloud", "room"])
+def test_scattered_pixel_runs_match_the_oracle(which, request):
     from oracle import binding as ob
-    hs = example if which == "example" else mesh
+    hs = request.getfixturevalue(which)
     dev, osc = pt.DeviceScene(hs), ob.OracleScene(hs)
     rng = np.random.default_rng(5)
     close, total = 0, 0
