@@ -321,6 +321,75 @@ def material_zoo(directory, dof=None, **settings):
     return write_scene_directory(directory, scene, default_settings(**settings))
 
 
+def random_box(directory, seed, **settings):
+    """A box with random contents drawn from `seed`: 4-14 spheres, rectangles and triangles at random places,
+    each with a material of a random type and random parameters (every material type can occur, with constant
+    or no maps, sometimes a constant transparency), one or two lights (a rectangle, a sphere, or both), a random
+    background colour, and sometimes a scattering medium as the background medium or inside a clear ball.
+    For parity tests: scenes nobody arranged by hand."""
+    rng = np.random.default_rng(seed)
+    u = lambda lo, hi: float(rng.uniform(lo, hi))
+    maps = list(_BASE_MAPS)
+    media = list(_BASE_MEDIA)
+    materials = list(_BASE_MATERIALS)
+    foggy = rng.random() < 0.25
+    if foggy:
+        media.append(_medium("haze_medium", "HomogenousScatteringMedium", [u(0.02, 0.3)] * 3, [u(0, 0.05), u(0, 0.05), u(0, 0.05)], 1.0))
+    media.append(_medium("murk_medium", "HomogenousScatteringMedium", [u(0.5, 4), u(0.5, 4), u(0.5, 4)], [u(0, 0.5), u(0, 0.5), u(0, 0.5)], 1.0,
+                         emission=(u(0, 0.3), 0, 0)))
+    outside = "haze_medium" if foggy else "air_medium"
+    subtypes = ["Diffuse", "Reflective", "Transparent", "Glossy", "MetallicMicrofacet", "ReflectiveMicrofacet",
+                "TransparentMicrofacet"]
+    objects = []
+    if rng.random() < 0.8:
+        objects += _cornell_shell()
+    else: # open scene: a ground plane and the background colour
+        objects.append({"name": "ground", "type": "Object", "subtype": "Plane",
+                        "parameters": {"position": [0, 0, 0], "v1": [1, 0, 0], "v2": [0, 0, -1], "material": "white_diffuse_material"}})
+    for i in range(int(rng.integers(4, 15))):
+        name = f"m{i}"
+        subtype = subtypes[int(rng.integers(0, len(subtypes)))]
+        maps.append(_map3(name + "_albedo", [u(0.1, 1), u(0.1, 1), u(0.1, 1)]))
+        maps.append(_map1(name + "_rough", u(0.02, 0.6)))
+        par = {"albedo_map": name + "_albedo", "roughness_map": name + "_rough", "surface_refractive_index": u(1.1, 2.2)}
+        if subtype in ("Reflective", "Glossy") and rng.random() < 0.5:
+            par["is_dielectric"] = False
+        if subtype == "MetallicMicrofacet":
+            par["surface_refractive_index"] = u(0.2, 1.5)
+            par["extinction_coefficient"] = u(1.5, 4)
+        if subtype in ("Transparent", "TransparentMicrofacet"):
+            inside = ["glass_medium", "cyan_glass_medium", "murk_medium", outside][int(rng.integers(0, 4))]
+            par.update(internal_medium=inside, external_medium=outside)
+        if rng.random() < 0.15:
+            maps.append(_map1(name + "_veil", u(0.2, 0.8)))
+            par["transparency_map"] = name + "_veil"
+        materials.append(_material(name + "_material", subtype, **par))
+        centre = [u(-0.9, 0.9), u(0.1, 1.6), u(-1.7, 0.6)]
+        kind = rng.random()
+        if kind < 0.55:
+            objects.append(_sphere(name, centre, u(0.08, 0.4), name + "_material"))
+        elif kind < 0.8:
+            v1 = rng.normal(size=3)
+            v2 = np.cross(v1, rng.normal(size=3))
+            objects.append(_rect(name, centre, [float(x) for x in v1], [float(x) for x in v2], u(0.2, 0.9), u(0.2, 0.9), name + "_material"))
+        else:
+            pts = [[c + u(-0.4, 0.4) for c in centre] for _ in range(3)]
+            objects.append({"name": name, "type": "Object", "subtype": "Triangle",
+                            "parameters": {"p1": pts[0], "p2": pts[1], "p3": pts[2], "material": name + "_material"}})
+    lights = int(rng.integers(1, 4)) # bit 0: rectangle light, bit 1: sphere light
+    if lights & 1:
+        objects.append(_rect("light_source", [u(-0.5, 0.5), 1.9999, u(-1.5, 0)], [1, 0, 0], [0, 0, 1], u(0.2, 0.8), u(0.2, 0.8), "light_source_material"))
+    if lights & 2:
+        maps += [_map1("bulb_strength", u(10, 60)), _map3("bulb_colour", [u(0.5, 1), u(0.5, 1), u(0.5, 1)])]
+        materials.append(_material("bulb_material", "Diffuse", albedo_map="white", emission_color_map="bulb_colour",
+                                   light_intensity_map="bulb_strength", is_light_source=True))
+        objects.append(_sphere("bulb", [u(-0.7, 0.7), u(1.2, 1.7), u(-1.4, 0.2)], u(0.05, 0.15), "bulb_material"))
+    scene = {"valuemaps": maps, "media": media, "materials": materials, "objects": objects, "background_medium": outside,
+             "background_color": [u(0, 0.3), u(0, 0.3), u(0, 0.3)] if rng.random() < 0.5 else [0.0, 0.0, 0.0],
+             "camera": _camera([u(-0.2, 0.2), u(0.7, 1.1), 1.9], u(82, 96), u(-6, 6), 0, 0.036, 0.036)}
+    return write_scene_directory(directory, scene, default_settings(**settings))
+
+
 def cloud_box(directory, fog=False, **settings):
     """The example box plus a homogeneous scattering volume bounded by an index-matched transparent
     sphere (which next-event estimation passes through), an emissive absorbing volume, and the

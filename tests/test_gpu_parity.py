@@ -68,6 +68,31 @@ def test_samples_match_oracle(scene_dirs, ob, name, tail_records):
     np.testing.assert_allclose(mean_g, mean_w, rtol=2e-3)
 
 
+@pytest.mark.parametrize("tail_records", [1048576, 0])
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_match_oracle(tmp_path, ob, seed, tail_records):
+    """Scenes nobody arranged by hand (scenes.random_box: random objects, materials of every type, media, lights);
+    the oracle is bit-exact against the reference on the same twelve scenes (tests/test_oracle_golden.py)."""
+    from pathtracing_amd import scenes
+    hs = pt.load_scene_directory(scenes.random_box(str(tmp_path), seed, WIDTH=48, HEIGHT=32))
+    n = hs.settings.width * hs.settings.height
+    osc, dev = ob.OracleScene(hs), pt.DeviceScene(hs)
+    primary = pt.make_job(0, n, 1, 0, 3)
+    want, got = osc.trace_primary(primary), dev.trace_primary(primary)
+    assert ((want[0] == got[0]) & (want[1] == got[1])).mean() >= 0.999
+    job = pt.make_job(0, n, 6, 1, 99 + seed)
+    want = osc.trace_samples(job)
+    pt.set_option("tail_records", tail_records)
+    try:
+        got = dev.trace_samples(job)
+    finally:
+        pt.set_option("tail_records", 1048576)
+    for w, g, what in zip(want, got, ("radiance", "position", "normal")):
+        frac = _close_fraction(g.reshape(-1, 3), w.reshape(-1, 3))
+        assert frac >= 0.999, f"seed {seed} {what}: only {frac:.5f} of the samples agree"
+    np.testing.assert_allclose(got[0].mean(axis=(0, 1)), want[0].mean(axis=(0, 1)), rtol=2e-3)
+
+
 @pytest.mark.parametrize("name", ["example", "mesh_rough_glass", "cloud"])
 def test_results_do_not_depend_on_batch_size_or_knobs(scene_dirs, name):
     hs = pt.load_scene_directory(scene_dirs[name])

@@ -138,3 +138,19 @@ def test_settings_variations_bit_exact_against_the_live_reference(built, name, o
     got = ob.OracleScene(hs).trace_samples(job, ob.stream_rng(11, 22, 33))
     for w, g in zip(want, got):
         assert np.array_equal(w, g, equal_nan=True)
+
+
+@pytest.mark.skipif(not ob.ref_available(), reason="the reference is built from /root/reference (build container only)")
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_bit_exact_against_the_live_reference(tmp_path, seed):
+    """Scenes nobody arranged by hand (scenes.random_box): random objects, materials of every type, media, lights."""
+    from pathtracing_amd import scenes
+    hs = pt.load_scene_directory(scenes.random_box(str(tmp_path), seed, WIDTH=32, HEIGHT=24))
+    n = hs.settings.width * hs.settings.height
+    job = pt.make_job(0, n, 3, 0, 0)
+    ref = ob.RefScene(hs)
+    ref.seed(5, 6, 7 + seed)
+    want = ref.trace_samples(job)
+    got = ob.OracleScene(hs).trace_samples(job, ob.stream_rng(5, 6, 7 + seed))
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g, equal_nan=True)
