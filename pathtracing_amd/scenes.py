@@ -325,7 +325,7 @@ def random_box(directory, seed, **settings):
     """A box with random contents drawn from `seed`: 4-14 spheres, rectangles and triangles at random places,
     each with a material of a random type and random parameters (every material type can occur, with constant
     or no maps, sometimes a constant transparency), one or two lights (a rectangle, a sphere, or both), a random
-    background colour, and sometimes a scattering medium as the background medium or inside a clear ball.
+    background colour, up to two small OBJ meshes, and sometimes a scattering medium as the background medium or inside a clear ball.
     For parity tests: scenes nobody arranged by hand."""
     rng = np.random.default_rng(seed)
     u = lambda lo, hi: float(rng.uniform(lo, hi))
@@ -387,6 +387,17 @@ def random_box(directory, seed, **settings):
     scene = {"valuemaps": maps, "media": media, "materials": materials, "objects": objects, "background_medium": outside,
              "background_color": [u(0, 0.3), u(0, 0.3), u(0, 0.3)] if rng.random() < 0.5 else [0.0, 0.0, 0.0],
              "camera": _camera([u(-0.2, 0.2), u(0.7, 1.1), 1.9], u(82, 96), u(-6, 6), 0, 0.036, 0.036)}
+    # zero to two OBJ meshes with one of the materials above, flat or smooth
+    for k in range(int(rng.integers(0, 3))):
+        os.makedirs(os.path.join(directory, "models"), exist_ok=True)
+        write_bumpy_sphere_obj(os.path.join(directory, "models", f"blob{k}.obj"), int(rng.integers(6, 20)), int(rng.integers(4, 12)),
+                               seed=int(rng.integers(1, 1000)), quads=bool(rng.random() < 0.5))
+        material = materials[int(rng.integers(0, len(materials)))]["name"]
+        objects.append({"name": f"blob{k}", "type": "Object", "subtype": "ObjectUnion",
+                        "parameters": {"file": f"models/blob{k}.obj", "material": material,
+                                       "enable_smooth_shading": bool(rng.random() < 0.5),
+                                       "center": [u(-0.7, 0.7), u(0.3, 1.2), u(-1.5, 0.3)], "size": u(0.25, 0.7),
+                                       "orientation": {"X": u(0, 90), "Y": u(0, 90), "Z": u(0, 90)}}})
     return write_scene_directory(directory, scene, default_settings(**settings))
 
 
