@@ -772,6 +772,12 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
         auto ior = [&](int medium) { return medium >= 0 ? media[static_cast<size_t>(medium)].ior : 1.0; };
         return most > 0 || (m.type == PTK_MAT_TRANSPARENT && ior(m.internal_medium) == ior(m.external_medium));
     };
+    // A connection to a point on an emissive mesh has no other object's distance to bound it (an analytic light
+    // is found by the object scan, which then limits the walk), so a triangle of another mesh beyond the light
+    // would pass for a blocker if the walk stopped at the first one it finds: such scenes walk every mesh exactly.
+    bool has_mesh_light = false;
+    for (const DevObject& o : objects)
+        if (o.type == PTK_OBJ_MESH && o.mat.is_light) has_mesh_light = true;
     std::vector<DevShape> shapes(objects.size());
     for (size_t i = 0; i < objects.size(); i++) {
         const DevObject& o = objects[i];
@@ -807,7 +813,7 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
             // transparency above zero or a Transparent material between media of equal refractive index;
             // a light has to be found exactly (its distance is compared with the sampled point's).
             const DevMaterial& m = o.mat;
-            sh.f[6] = (!lets_light_through(m) && !m.is_light) ? 1.0 : 0.0;
+            sh.f[6] = (!lets_light_through(m) && !m.is_light && !has_mesh_light) ? 1.0 : 0.0;
         }
         else if (o.type == PTK_OBJ_PLANE || o.type == PTK_OBJ_RECTANGLE) {
             const double v[14] = {o.px, o.py, o.pz, o.nx, o.ny, o.nz, o.v1x, o.v1y, o.v1z, o.v2x, o.v2y, o.v2z, o.L1, o.L2};

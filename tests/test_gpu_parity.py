@@ -69,7 +69,9 @@ def test_samples_match_oracle(scene_dirs, ob, name, tail_records):
 
 
 @pytest.mark.parametrize("tail_records", [1048576, 0])
-@pytest.mark.parametrize("seed", range(12))
+# 74, 88, 96: an emissive mesh next to an opaque one (a connection to the former must not stop at the first triangle
+# of the latter it meets, which may lie beyond the light)
+@pytest.mark.parametrize("seed", list(range(12)) + [74, 88, 96])
 def test_random_scenes_match_oracle(tmp_path, ob, seed, tail_records):
     """Scenes nobody arranged by hand (scenes.random_box: random objects, materials of every type, media, lights);
     the oracle is bit-exact against the reference on the same twelve scenes (tests/test_oracle_golden.py)."""

@@ -1,0 +1,35 @@
+"""GPU against the CPU oracle on many generated scenes (scenes.random_box): prints, per seed, the share of samples
+whose radiance / first-surface position / normal agree within 1e-9 and the ratio of the mean radiances.
+usage: python tools/random_sweep.py <first_seed> <last_seed>"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pathtracing_amd as pt
+from pathtracing_amd import scenes
+from oracle import binding as ob
+
+pt.init(0)
+first, last = int(sys.argv[1]), int(sys.argv[2])
+worst = 1.0
+for seed in range(first, last + 1):
+    hs = pt.load_scene_directory(scenes.random_box(tempfile.mkdtemp(prefix="ptk_sweep_"), seed, WIDTH=48, HEIGHT=32))
+    n = hs.settings.width * hs.settings.height
+    job = pt.make_job(0, n, 6, 1, 99 + seed)
+    want = ob.OracleScene(hs).trace_samples(job)
+    fracs = []
+    for tail in (1048576, 0):
+        pt.set_option("tail_records", tail)
+        got = pt.DeviceScene(hs).trace_samples(job)
+        for w, g in zip(want, got):
+            ok = np.isclose(g.reshape(-1, 3), w.reshape(-1, 3), rtol=1e-9, atol=1e-12, equal_nan=True).all(axis=1)
+            fracs.append(ok.mean())
+    pt.set_option("tail_records", 1048576)
+    ratio = got[0].mean() / want[0].mean()
+    worst = min(worst, min(fracs))
+    flag = "" if min(fracs) >= 0.999 and abs(ratio - 1) < 2e-3 else "  <-- outside the test tolerances"
+    print(seed, " ".join(f"{f:.5f}" for f in fracs), f"mean ratio {ratio:.6f}{flag}", flush=True)
+print("worst share", worst)
