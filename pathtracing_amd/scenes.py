@@ -321,11 +321,12 @@ def material_zoo(directory, dof=None, **settings):
     return write_scene_directory(directory, scene, default_settings(**settings))
 
 
-def random_box(directory, seed, **settings):
+def random_box(directory, seed, extras=False, **settings):
     """A box with random contents drawn from `seed`: 4-14 spheres, rectangles and triangles at random places,
     each with a material of a random type and random parameters (every material type can occur, with constant
     or no maps, sometimes a constant transparency), one or two lights (a rectangle, a sphere, or both), a random
     background colour, up to two small OBJ meshes, and sometimes a scattering medium as the background medium or inside a clear ball.
+    `extras`: additionally, sometimes, a thin-lens camera, file textures for albedo or roughness, a cut-out texture.
     For parity tests: scenes nobody arranged by hand."""
     rng = np.random.default_rng(seed)
     u = lambda lo, hi: float(rng.uniform(lo, hi))
@@ -346,7 +347,8 @@ def random_box(directory, seed, **settings):
     else: # open scene: a ground plane and the background colour
         objects.append({"name": "ground", "type": "Object", "subtype": "Plane",
                         "parameters": {"position": [0, 0, 0], "v1": [1, 0, 0], "v2": [0, 0, -1], "material": "white_diffuse_material"}})
-    for i in range(int(rng.integers(4, 15))):
+    n_own = int(rng.integers(4, 15))
+    for i in range(n_own):
         name = f"m{i}"
         subtype = subtypes[int(rng.integers(0, len(subtypes)))]
         maps.append(_map3(name + "_albedo", [u(0.1, 1), u(0.1, 1), u(0.1, 1)]))
@@ -398,6 +400,30 @@ def random_box(directory, seed, **settings):
                                        "enable_smooth_shading": bool(rng.random() < 0.5),
                                        "center": [u(-0.7, 0.7), u(0.3, 1.2), u(-1.5, 0.3)], "size": u(0.25, 0.7),
                                        "orientation": {"X": u(0, 90), "Y": u(0, 90), "Z": u(0, 90)}}})
+    if extras: # drawn from a generator of their own, so that a seed gives the same base scene with or without them
+        xr = np.random.default_rng(1_000_003 + seed)
+        if xr.random() < 0.35:
+            scene["camera"].update({"depth_of_field_mode": "circle" if xr.random() < 0.5 else "square",
+                                    "focus_distance": float(xr.uniform(1.5, 3.5)), "aperture_size": float(xr.uniform(0.02, 0.15))})
+        own = materials[len(_BASE_MATERIALS):len(_BASE_MATERIALS) + n_own] # the materials made above (the base ones are shared)
+        for k in range(int(xr.integers(0, 3))): # file textures in place of constant maps
+            if not own:
+                break
+            m = own[int(xr.integers(0, len(own)))]
+            w, h = int(xr.integers(2, 40)), int(xr.integers(2, 40))
+            if xr.random() < 0.6:
+                write_map_file(os.path.join(directory, "maps", f"tex{k}.map"), value_noise(w, h, 3, seed=int(xr.integers(1, 999))))
+                maps.append(_map_file(f"tex{k}", "ValueMap3D", f"maps/tex{k}.map"))
+                m["parameters"]["albedo_map"] = f"tex{k}"
+            else:
+                write_map_file(os.path.join(directory, "maps", f"tex{k}.map"), 0.03 + 0.5 * value_noise(w, h, 1, seed=int(xr.integers(1, 999)))[:, :, 0])
+                maps.append(_map_file(f"tex{k}", "ValueMap1D", f"maps/tex{k}.map"))
+                m["parameters"]["roughness_map"] = f"tex{k}"
+        if xr.random() < 0.25 and own: # a cut-out: transparency from a checker texture
+            m = own[int(xr.integers(0, len(own)))]
+            write_map_file(os.path.join(directory, "maps", "cut.map"), checker(16, 16, int(xr.integers(2, 8)), 0.0, float(xr.uniform(0.3, 1.0))))
+            maps.append(_map_file("cut", "ValueMap1D", "maps/cut.map"))
+            m["parameters"]["transparency_map"] = "cut"
     return write_scene_directory(directory, scene, default_settings(**settings))
 
 

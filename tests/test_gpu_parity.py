@@ -73,10 +73,11 @@ def test_samples_match_oracle(scene_dirs, ob, name, tail_records):
 # of the latter it meets, which may lie beyond the light)
 @pytest.mark.parametrize("seed", list(range(12)) + [74, 88, 96])
 def test_random_scenes_match_oracle(tmp_path, ob, seed, tail_records):
-    """Scenes nobody arranged by hand (scenes.random_box: random objects, materials of every type, media, lights);
+    """Scenes nobody arranged by hand (scenes.random_box: random objects, materials of every type, media, lights; odd seeds
+    also file textures, cut-outs and thin-lens cameras);
     the oracle is bit-exact against the reference on the same twelve scenes (tests/test_oracle_golden.py)."""
     from pathtracing_amd import scenes
-    hs = pt.load_scene_directory(scenes.random_box(str(tmp_path), seed, WIDTH=48, HEIGHT=32))
+    hs = pt.load_scene_directory(scenes.random_box(str(tmp_path), seed, extras=bool(seed % 2), WIDTH=48, HEIGHT=32))
     n = hs.settings.width * hs.settings.height
     osc, dev = ob.OracleScene(hs), pt.DeviceScene(hs)
     primary = pt.make_job(0, n, 1, 0, 3)

@@ -145,7 +145,7 @@ def test_settings_variations_bit_exact_against_the_live_reference(built, name, o
 def test_random_scenes_bit_exact_against_the_live_reference(tmp_path, seed):
     """Scenes nobody arranged by hand (scenes.random_box): random objects, materials of every type, media, lights."""
     from pathtracing_amd import scenes
-    hs = pt.load_scene_directory(scenes.random_box(str(tmp_path), seed, WIDTH=32, HEIGHT=24))
+    hs = pt.load_scene_directory(scenes.random_box(str(tmp_path), seed, extras=bool(seed % 2), WIDTH=32, HEIGHT=24))
     n = hs.settings.width * hs.settings.height
     job = pt.make_job(0, n, 3, 0, 0)
     ref = ob.RefScene(hs)
