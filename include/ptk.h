@@ -288,7 +288,11 @@ typedef struct PtkDenoiseTask {
 } PtkDenoiseTask;
 
 /* Replaces denoise() (src/denoise.cpp:203-212): applies the tasks in order to `image`
- * in place, guided by `position` and `normal`; host buffers double[H*W*3]. */
+ * in place, guided by `position` and `normal`; host buffers double[H*W*3].
+ * The pipeline is checked before anything runs and rejected with PTK_ERR_INVALID when a median window is even,
+ * above 15 or larger than the image (the reference's own check, src/denoise.cpp:149-153), or when the a-trous taps of
+ * the last iteration (2^iterations pixels from the centre) reach further than the one reflection at the border covers
+ * (2^iterations > min(width, height) - 1): the reference reads outside its buffers in that case. */
 int ptk_denoise(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t width, int32_t height, double* image,
                 const double* position, const double* normal);
 /* Same on device buffers (image is updated in place; `scratch` is a device buffer of

@@ -89,8 +89,13 @@ __global__ __launch_bounds__(TILE_W* TILE_H) void k_atrous(int W, int H, const d
 }
 
 // 9-element median by a 19-exchange sorting network (kernel_size 3).
+// Order of the median's values: ascending, NaN after everything else.  (The reference hands the window to
+// std::nth_element, whose result is unspecified once a NaN breaks the ordering; here a window's median is NaN only
+// when more than half of it is.)
+__device__ __forceinline__ bool comes_before(double a, double b) { return a < b || (!isnan(a) && isnan(b)); }
 __device__ __forceinline__ void cswap(double& a, double& b) {
-    const double lo = fmin(a, b), hi = fmax(a, b);
+    const bool swap = comes_before(b, a);
+    const double lo = swap ? b : a, hi = swap ? a : b;
     a = lo;
     b = hi;
 }
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(TILE_W* TILE_H) void k_median_general(int W, int H,
                 const int jx = reflect_coordinate(gx + j % kernel_size - offset, W);
                 const int jy = reflect_coordinate(gy + j / kernel_size - offset, H);
                 const double vj = image[3 * (static_cast<size_t>(W) * jy + jx) + c];
-                rank += (vj < vi || (vj == vi && j < i)) ? 1 : 0;
+                rank += (comes_before(vj, vi) || (!comes_before(vi, vj) && j < i)) ? 1 : 0;
             }
             if (rank == target) med[c] = vi;
         }

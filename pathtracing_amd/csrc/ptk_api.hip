@@ -1102,6 +1102,24 @@ int ptk_denoise_device(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t wid
     if ((!tasks && n_tasks > 0) || width < 1 || height < 1 || !d_image || !d_position || !d_normal || !d_scratch)
         return fail(PTK_ERR_INVALID, "ptk_denoise_device: bad argument");
     const size_t bytes = static_cast<size_t>(width) * static_cast<size_t>(height) * 24;
+    // The whole pipeline is checked before its first kernel runs.  An a-trous tap lies up to 2^iterations pixels from
+    // its centre in the last iteration, and the border rule reflects a coordinate once (src/denoise.cpp:20-38): a tap
+    // further out than the image is wide or high lands outside the buffers (the reference reads there all the same).
+    for (int32_t t = 0; t < n_tasks; t++) {
+        const PtkDenoiseTask& task = tasks[t];
+        if (task.mode == PTK_DENOISE_MEDIAN) {
+            if (task.kernel_size < 1 || task.kernel_size % 2 == 0 || task.kernel_size > 15)
+                return fail(PTK_ERR_INVALID, "ptk_denoise: median kernel_size must be odd and at most 15");
+            if (task.kernel_size > std::min(width, height))
+                return fail(PTK_ERR_INVALID, "Median filter kernel size is too large for this image size.");
+            continue;
+        }
+        if (task.mode != PTK_DENOISE_ATROUS) return fail(PTK_ERR_INVALID, "ptk_denoise: unknown mode");
+        if (task.iterations < 0 || task.iterations > 30) return fail(PTK_ERR_INVALID, "ptk_denoise: a-trous iterations must be between 0 and 30");
+        if (task.iterations > 0 && (1ll << task.iterations) > std::min(width, height) - 1)
+            return fail(PTK_ERR_INVALID, "ptk_denoise: the a-trous taps of the last iteration (2^iterations pixels out) reach beyond one reflection at the "
+                                         "border of an image this small");
+    }
     double* src = d_image;
     double* dst = d_scratch;
     for (int32_t t = 0; t < n_tasks; t++) { // denoise() src/denoise.cpp:203-212

@@ -203,6 +203,20 @@ def test_denoise_matches_oracle(scene_dirs, ob):
         np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-13)
 
 
+def test_random_denoise_pipelines_match_oracle(ob):
+    """Random frames (1x1 to 89x69, fireflies, zero and NaN pixels) through random pipelines (tools/random_denoise.py):
+    equal to the oracle within 1e-10, and a pipeline whose taps would leave a small frame is refused."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "random_denoise", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "random_denoise.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    verdicts = {seed: tool.check_case(seed, pt, ob) for seed in range(1, 81)}
+    assert all(v in ("ok", "refused") for v in verdicts.values()), {s: v for s, v in verdicts.items() if v not in ("ok", "refused")}
+    assert sum(v == "refused" for v in verdicts.values()) >= 5 and sum(v == "ok" for v in verdicts.values()) >= 40
+
+
 def test_statistics_count_paths_and_rays(scene_dirs, ob):
     hs = pt.load_scene_directory(scene_dirs["example"])
     n = hs.settings.width * hs.settings.height
