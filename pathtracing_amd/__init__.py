@@ -44,12 +44,12 @@ def device_lib():
 
 def _check_host(rc):
     if rc != 0:
-        raise PtkError(host_lib().ptk_host_last_error().decode())
+        raise PtkError(host_lib().ptk_host_last_error().decode(errors="replace"))
 
 
 def _check_dev(rc):
     if rc != 0:
-        raise PtkError(device_lib().ptk_last_error().decode())
+        raise PtkError(device_lib().ptk_last_error().decode(errors="replace"))
 
 
 def _dp(a):

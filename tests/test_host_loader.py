@@ -218,3 +218,13 @@ def test_accumulation_buffer_files(tmp_path):
     a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(3, 4, 3))
     assert list(a[1, 2]) == [1.5, 2.5, 3.5]
     lib.ptk_host_unmap_buffer(ptr, size, fd)
+
+
+def test_mutated_scene_directories_load_or_fail_with_a_message():
+    """tools/fuzz_loader.py in a process of its own (a crash of the loader would take the test runner with it)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_loader.py"), "0", "120"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    assert "refused" in run.stdout.splitlines()[-1]
