@@ -154,3 +154,24 @@ def test_random_scenes_bit_exact_against_the_live_reference(tmp_path, seed):
     got = ob.OracleScene(hs).trace_samples(job, ob.stream_rng(5, 6, 7 + seed))
     for w, g in zip(want, got):
         assert np.array_equal(w, g, equal_nan=True)
+
+
+@pytest.mark.skipif(not ob.ref_available(), reason="the reference is built from /root/reference (build container only)")
+def test_random_denoise_pipelines_bit_exact_against_the_live_reference():
+    """Random frames and pipelines (tools/random_denoise.py), those the reference can run without leaving its buffers."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("random_denoise", os.path.join(root, "tools", "random_denoise.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    checked = 0
+    for seed in range(1, 121):
+        image, position, normal, pipeline, valid = tool.make_case(seed)
+        if not valid:
+            continue
+        tasks = pt.make_denoise_tasks(pipeline)
+        want = ob.ref_denoise(tasks, image, position, normal)
+        got = ob.oracle_denoise(tasks, image, position, normal)
+        assert np.array_equal(want, got, equal_nan=True), (seed, pipeline)
+        checked += 1
+    assert checked >= 60
