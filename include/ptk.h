@@ -196,13 +196,24 @@ typedef struct PtkStats {
     /* Vertices shaded per class (PTK_MAT_* order, then medium scattering). */
     uint64_t class_vertices[8];
     uint64_t traversed_rays, nodes_visited, triangles_tested; /* k_traverse */
+    /* Entries the hierarchy walks had to drop because their stack was full.  Always 0: the host bounds the
+     * stack every hierarchy needs when it builds it; a non-zero value would mean missed triangles. */
+    uint64_t stack_overflows;
 } PtkStats;
 
-/* Selects the GPU for this process (hipSetDevice) and creates the library's stream.
- * Fails with PTK_ERR_DEVICE when no gfx950 device is usable: there is no CPU path. */
+/* Selects the GPU for the calling thread (hipSetDevice) and, the first time a device is
+ * named, creates the library's stream on it.  Fails with PTK_ERR_DEVICE when no gfx950
+ * device is usable: there is no CPU path.
+ * Several devices in one process: every host thread calls ptk_init with its own device
+ * and then creates its scenes and films; those remember their device, so later calls on
+ * them may come from any thread (one thread at a time per scene or film).  Calls without
+ * a scene or film argument (ptk_sync, ptk_stream, ptk_film_create, ptk_denoise*) act on
+ * the device of the calling thread's last ptk_init, or of the process's last one for a
+ * thread that never called it.  Replaces the reference's thread pool over one shared
+ * scene (app/pathtracer.cpp:356-365) as the unit of host parallelism. */
 int ptk_init(int device);
 const char* ptk_last_error(void);
-/* Blocks until all work queued by the library on its stream has finished. */
+/* Blocks until all work queued by the library on the calling thread's device has finished. */
 int ptk_sync(void);
 /* The library's HIP stream as an opaque handle (hipStream_t). */
 void* ptk_stream(void);
@@ -248,7 +259,11 @@ int ptk_film_device_pointers(PtkFilm* film, double** image, double** position, d
 
 /* Replaces raytrace_section (app/pathtracer.cpp:237-275): traces the job and folds
  * the per-pixel sample means into the film with increment_average's running-mean
- * arithmetic (app/pathtracer.cpp:232-235).  Asynchronous on the library's stream. */
+ * arithmetic (app/pathtracer.cpp:232-235).  The job is cut into batches of whole pixels;
+ * the call returns once the last batch has been traced (it reads that batch's ray
+ * statistics back), with only the film update of the last batch still queued on the
+ * stream: ptk_sync() or any ptk_film_* copy waits for it.  The film must live on the
+ * scene's device. */
 int ptk_render(PtkScene* scene, PtkFilm* film, const PtkRenderJob* job);
 
 /* Same, on caller-owned host buffers (the mmap'd temp/raw_*.dat files): uploads the
@@ -265,13 +280,20 @@ int ptk_reset_stats(PtkScene* scene);
  * when enabled, HIP events bracket every kernel family on the library's stream and the
  * *_ms fields of PtkStats accumulate device time.  Also enabled by PTK_PROFILE=1. */
 int ptk_set_profiling(int enabled);
-/* Tuning knobs, by name (no counterpart in the reference).  "tail_records": once at most this many paths of a
+/* Tuning knobs, by name, process-wide (no counterpart in the reference).  "tail_records": once at most this many paths of a
  * batch are left, one kernel launch follows each of them to its end instead of running three launches per bounce
  * (0 switches that off; default 1048576, upper limit 16777216; scenes with meshes switch at four times the value).  "specialised_kernels": 1 (default) traces a scene with the
  * kernels compiled for what it contains (no triangles, no texture coordinates, tables small enough for on-chip
  * copies, ...); 0 makes every scene use the general kernels that scenes with many objects get.  Unknown names and
  * values out of range fail with PTK_ERR_INVALID.  Results do not depend on any knob. */
 int ptk_set_option(const char* name, int64_t value);
+
+/* Device self-test (no counterpart in the reference): sends `n_records` (1 to 2^22) path records through the
+ * asynchronous memory -> on-chip staging -> register path the shading kernels prefetch their records with, in a
+ * kernel with other loads in flight and some lanes switched off, and reports how many arrived different from their
+ * source.  0 is the only healthy answer; a regression in the hand-placed wait counts of that path shows here
+ * instead of as a rare wrong pixel. */
+int ptk_selftest_record_staging(int64_t n_records, int64_t* mismatches);
 
 /* ---- denoise ---------------------------------------------------------------------- */
 

@@ -53,7 +53,20 @@ def _check_dev(rc):
 
 
 def _dp(a):
-    return None if a is None else a.ctypes.data_as(_ffi.dptr)
+    """Pointer to a float64, C-contiguous array (the layout every buffer argument of the C ABI has)."""
+    if a is None:
+        return None
+    if not isinstance(a, np.ndarray) or a.dtype != np.float64 or not a.flags["C_CONTIGUOUS"]:
+        raise TypeError("expected a C-contiguous numpy array of float64")
+    return a.ctypes.data_as(_ffi.dptr)
+
+
+def _u64p(a):
+    if a is None:
+        return None
+    if not isinstance(a, np.ndarray) or a.dtype != np.uint64 or not a.flags["C_CONTIGUOUS"]:
+        raise TypeError("expected a C-contiguous numpy array of uint64")
+    return a.ctypes.data_as(_ffi.u64ptr)
 
 
 # ------------------------------------------------------------------------------------------
@@ -210,8 +223,11 @@ class Film:
         _check_dev(device_lib().ptk_film_clear(self._handle))
 
     def upload(self, image=None, position=None, normal=None, counters=None):
-        cp = None if counters is None else counters.ctypes.data_as(_ffi.u64ptr)
-        _check_dev(device_lib().ptk_film_upload(self._handle, _dp(image), _dp(position), _dp(normal), cp))
+        n = self.width * self.height
+        for a, size in ((image, 3 * n), (position, 3 * n), (normal, 3 * n), (counters, n)):
+            if a is not None and a.size != size:
+                raise ValueError("buffer size does not match the film")
+        _check_dev(device_lib().ptk_film_upload(self._handle, _dp(image), _dp(position), _dp(normal), _u64p(counters)))
 
     def download(self):
         shape = (self.height, self.width, 3)
@@ -243,7 +259,8 @@ class DeviceScene:
 
     def __init__(self, host_scene, max_paths_in_flight=0):
         init(_dev_initialised if _dev_initialised is not None else 0)
-        self.settings = host_scene.desc.settings
+        # a copy: the description belongs to the host scene, which may be closed while this scene lives on
+        self.settings = PtkSettings.from_buffer_copy(host_scene.desc.settings)
         h = C.c_void_p()
         _check_dev(device_lib().ptk_scene_create(C.byref(host_scene.desc), int(max_paths_in_flight), C.byref(h)))
         self._handle = h
@@ -273,8 +290,11 @@ class DeviceScene:
         _check_dev(device_lib().ptk_render(self._handle, film._handle, C.byref(job)))
 
     def render_host(self, job, image, position, normal, counters):
+        n = self.n_pixels
+        if image.size != 3 * n or position.size != 3 * n or normal.size != 3 * n or counters.size != n:
+            raise ValueError("buffer size does not match the scene's image")
         _check_dev(device_lib().ptk_render_host(self._handle, C.byref(job), _dp(image), _dp(position), _dp(normal),
-                                                counters.ctypes.data_as(_ffi.u64ptr)))
+                                                _u64p(counters)))
 
     def stats(self):
         s = PtkStats()

@@ -69,7 +69,7 @@ class PtkStats(C.Structure):
                 ("traverse_ms", C.c_double), ("bounce_launches", C.c_uint64), ("bin_launches", C.c_uint64),
                 ("traverse_launches", C.c_uint64), ("bounce_bytes", C.c_uint64), ("bin_bytes", C.c_uint64),
                 ("traverse_bytes", C.c_uint64), ("class_vertices", C.c_uint64 * 8), ("traversed_rays", C.c_uint64),
-                ("nodes_visited", C.c_uint64), ("triangles_tested", C.c_uint64)]
+                ("nodes_visited", C.c_uint64), ("triangles_tested", C.c_uint64), ("stack_overflows", C.c_uint64)]
 
 
 class PtkDenoiseTask(C.Structure):
@@ -130,6 +130,7 @@ DEVICE_PROTOTYPES = {
     "ptk_reset_stats": (C.c_int, [C.c_void_p]),
     "ptk_set_profiling": (C.c_int, [C.c_int]),
     "ptk_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
+    "ptk_selftest_record_staging": (C.c_int, [C.c_int64, C.POINTER(C.c_int64)]),
     "ptk_denoise": (C.c_int, [C.POINTER(PtkDenoiseTask), C.c_int32, C.c_int32, C.c_int32, dptr, dptr, dptr]),
     "ptk_denoise_device": (C.c_int, [C.POINTER(PtkDenoiseTask), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),

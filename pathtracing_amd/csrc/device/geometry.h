@@ -85,6 +85,7 @@ struct TraversalStack {
     LdsStackEntry* lds; // this thread's column: element d at lds[d * blockDim.x]
     int stride;
     StackEntry* spill;  // [SPILL_STACK_DEPTH]
+    uint32_t* overflows; // device counter of pushes that found the stack full (uniform; stays zero, see push)
     int sp;
     uint32_t nodes_visited, triangles_tested; // statistics of k_traverse
     PTK_DEV void push(int32_t node, float tnear) {
@@ -93,7 +94,13 @@ struct TraversalStack {
             lds[sp * stride].tnear = tnear;
         }
         else if (sp < LDS_STACK_DEPTH + SPILL_STACK_DEPTH) spill[sp - LDS_STACK_DEPTH] = StackEntry{node, tnear};
-        else return; // deeper than any tree the builder produces (its depth is bounded)
+        else {
+            // The host builds no tree that needs more entries than the stack has (build_bvh4 bounds the need and
+            // ptk_scene_create checks it), so this is never reached; were it, the entry would be lost and the
+            // count of such losses says so (PtkStats::stack_overflows).
+            atomicAdd(overflows, 1u);
+            return;
+        }
         sp++;
     }
     PTK_DEV StackEntry pop() {

@@ -17,6 +17,14 @@ uint32_t chunk_rounds(uint32_t bound);
 // entries per class block_counts needs for pools of up to `records` records under chunk_rounds()
 uint32_t chunk_capacity(uint32_t records);
 
+// What a launcher needs to know about the device it launches on and about the process-wide tuning knobs.
+struct LaunchContext {
+    hipStream_t stream;
+    uint32_t compute_units; // of the device the stream belongs to: sizes the grids of the persistent kernels
+    bool specialised;       // false: every scene runs the general kernels (all features compiled in, tables read from
+                            // memory) instead of the ones specialised on its contents; the results are the same
+};
+
 // In every launcher `bound` is an upper bound of the number of records, used only to size the grid;
 // the kernels read the true counts from device memory (*previous: the summary of the bounce that wrote
 // the pool they read; *info: the summary of the sorted list they produce or walk), so the host never
@@ -29,27 +37,22 @@ void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_
                 uint32_t* block_counts, uint32_t count_stride, BinInfo* info, uint32_t* list_out);
 // one vertex of every path; leaves the class counts of `out` in block_counts;
 // statistics: [STATISTICS_SLOTS][N_STATISTICS] per-block slots; queues: used by scenes with meshes
-void launch_bounce(hipStream_t s, uint32_t bound, uint32_t rounds, const DevScene& sc, const BatchParams& b, const PathPool& in,
+void launch_bounce(const LaunchContext& lc, uint32_t bound, uint32_t rounds, const DevScene& sc, const BatchParams& b, const PathPool& in,
                    const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info, uint32_t* block_counts,
                    uint32_t count_stride, unsigned long long* statistics, const DeferQueues& queues);
 // Name (as the profiler prints it) of the k_bounce instantiation launch_bounce uses for this scene.
-std::string bounce_kernel_name(const DevScene& sc);
-// false: every scene runs the general kernels (all features compiled in, tables read from memory) instead of the
-// ones specialised on its contents; the results are the same.
-void set_specialised_kernels(bool on);
-// number of compute units of the device in use (sizes the grids of the persistent kernels; 256 until told otherwise)
-void set_compute_units(int n);
+std::string bounce_kernel_name(const DevScene& sc, bool specialised);
 // Every remaining bounce of the paths in `list` (at most `bound` of them) in one launch.  TAIL_RECORDS is the default
 // count at which a batch switches to it (scenes with meshes: four times that), measured on one MI355X: the bounces of
 // fewer than a million paths no longer fill the device, and three launches per bounce cost more than the sorting
 // they buy.
 constexpr uint32_t TAIL_RECORDS = 1u << 20;
-void launch_tail(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
+void launch_tail(const LaunchContext& lc, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
                  const SampleResults& res, const uint32_t* list, BinInfo* info, unsigned long long* statistics);
 // Scenes with meshes, after launch_bounce: the hierarchy walks of the queued rays (statistics slots: [0] rays,
 // [1] nodes visited, [2] triangles tested), then the deferred vertices.
-void launch_traverse(hipStream_t s, uint32_t bound, const DevScene& sc, const DeferQueues& queues, unsigned long long* statistics);
-void launch_bounce_resume(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
+void launch_traverse(const LaunchContext& lc, uint32_t bound, const DevScene& sc, const DeferQueues& queues, unsigned long long* statistics);
+void launch_bounce_resume(const LaunchContext& lc, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
                           const SampleResults& res, uint32_t* block_counts, uint32_t count_stride, unsigned long long* statistics,
                           const DeferQueues& queues);
 void launch_sum_statistics(hipStream_t s, const unsigned long long* slots, unsigned long long* totals);
@@ -59,6 +62,11 @@ void launch_gather_samples(hipStream_t s, const BatchParams& b, const SampleResu
                            double* position, double* normal);
 void launch_primary(hipStream_t s, const DevScene& sc, const BatchParams& b, int32_t* object_index, int32_t* primitive_index,
                     double* distance, double* position, double* normal);
+
+// Copies record list[i] of `in` to record i of `out` (i < n, i % 5 != 3) through the LDS staging k_bounce uses;
+// `blocks` blocks of 256 threads, `noise` holds noise_mask + 1 doubles, `sink` blocks * 256.
+void launch_selftest_staging(hipStream_t s, uint32_t blocks, const PathPool& in, const PathPool& out, const uint32_t* list, uint32_t n,
+                             const double* noise, uint32_t noise_mask, double* sink);
 
 // denoise.hip
 void launch_atrous(hipStream_t s, int width, int height, const double* image_in, double* image_out, const double* position,

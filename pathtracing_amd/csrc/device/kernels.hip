@@ -135,7 +135,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_WAVES) void 
                                                                                            unsigned long long* statistics) {
     __shared__ StackEntry lds_stack[LDS_STACK_DEPTH * BLOCK];
     __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
-    PTK_TRAVERSAL_STACK(st, lds_stack);
+    PTK_TRAVERSAL_STACK(st, lds_stack, sc);
     const uint32_t n = queues.counters[0];
     // the list of meshes, in LDS when it fits: a ray consults it whenever it moves on to its next mesh
     __shared__ DevMeshRef lds_meshes[TRAVERSE_LDS_MESHES];
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_samples(BatchParams b, SampleR
 __global__ __launch_bounds__(BLOCK) void k_primary(DevScene sc, BatchParams b, int32_t* object_index, int32_t* primitive_index,
                                                    double* distance, double* position, double* normal) {
     __shared__ StackEntry lds_stack[LDS_STACK_DEPTH * BLOCK];
-    PTK_TRAVERSAL_STACK(st, lds_stack);
+    PTK_TRAVERSAL_STACK(st, lds_stack, sc);
     for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < b.n_pixels; p += gridDim.x * BLOCK) {
         const uint32_t pixel = static_cast<uint32_t>(b.start_idx) + p;
         Rng rng{rng_key(b.seed, pixel, b.sample_offset), 0};
@@ -339,6 +339,47 @@ __global__ __launch_bounds__(BLOCK) void k_primary(DevScene sc, BatchParams b, i
         normal[3 * p + 1] = n.y;
         normal[3 * p + 2] = n.z;
     }
+}
+
+// Self-test of the record prefetch through LDS (request_record / staged_record, the pair k_bounce stages its
+// records with): record list[i] of `in` travels memory -> LDS -> registers -> record i of `out`, in the same
+// two-step pipeline as k_bounce (the request for the next round is issued in the middle of the current one), with
+// some lanes switched off and unrelated vector loads in flight, so a missing or wrong wait count between the
+// asynchronous load into LDS and the LDS read shows up as a record that differs from its source.
+__global__ __launch_bounds__(BLOCK) void k_selftest_staging(PathPool in, PathPool out, const uint32_t* list, uint32_t n,
+                                                            const double* noise, uint32_t noise_mask, double* sink) {
+    __shared__ double2 lds_record[N_PLANES * BLOCK];
+    double2* const wave_stage = lds_record + 64 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double acc = 0;
+    const uint32_t stride = gridDim.x * BLOCK;
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    auto active = [&](uint32_t k) { return k < n && (k % 5u) != 3u; };
+    if (active(i)) request_record(in, list[i], wave_stage);
+    for (; i - threadIdx.x < n; i += stride) { // block-uniform trip count
+        Record cur{};
+        if (active(i)) cur = staged_record(lds_record);
+        acc += noise[(i * 2654435761u) & noise_mask]; // a load that is still in flight when the next request is issued
+        if (active(i + stride)) request_record(in, list[i + stride], wave_stage);
+        acc += noise[(i * 40503u + 17u) & noise_mask];
+        if (active(i)) {
+            st2(out, PL_RAY0, i, cur.r0.x, cur.r0.y);
+            st2(out, PL_RAY1, i, cur.r1.x, cur.r1.y);
+            st2(out, PL_RAY2, i, cur.r2.x, cur.r2.y);
+            st2(out, PL_THR0, i, cur.t0.x, cur.t0.y);
+            st2(out, PL_THR1, i, cur.t1.x, cur.t1.y);
+            st2(out, PL_SAV0, i, cur.v0.x, cur.v0.y);
+            st2(out, PL_SAV1, i, cur.v1.x, cur.v1.y);
+            st2(out, PL_COL, i, cur.cc.x, cur.cc.y);
+            stu4(out, PL_HIT, i, cur.hit.x, cur.hit.y, cur.hit.z, cur.hit.w);
+            stu4(out, PL_IDS, i, cur.ids.x, cur.ids.y, cur.ids.z, cur.ids.w);
+        }
+    }
+    sink[blockIdx.x * BLOCK + threadIdx.x] = acc;
+}
+
+void launch_selftest_staging(hipStream_t s, uint32_t blocks, const PathPool& in, const PathPool& out, const uint32_t* list, uint32_t n,
+                             const double* noise, uint32_t noise_mask, double* sink) {
+    hipLaunchKernelGGL(k_selftest_staging, dim3(blocks), dim3(BLOCK), 0, s, in, out, list, n, noise, noise_mask, sink);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -389,21 +430,12 @@ void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_
 }
 
 // ---- choice of kernel variant (see variants.h) ---------------------------------------------------
-static bool g_specialised = true;
-static uint32_t g_compute_units = 256; // of the device in use: sizes the grids of the persistent kernels
-void set_compute_units(int n) {
-    if (n > 0) g_compute_units = static_cast<uint32_t>(n);
-}
-void set_specialised_kernels(bool on) {
-    g_specialised = on;
-}
-
 namespace {
 struct Variant {
     bool tris, uv, defer, pass, cache;
 };
-Variant variant_of(const DevScene& sc) {
-    Variant v{sc.has_triangles != 0, sc.needs_uv != 0, sc.has_meshes != 0, sc.has_pass_through != 0, g_specialised && sc.tables_fit_lds != 0};
+Variant variant_of(const DevScene& sc, bool specialised) {
+    Variant v{sc.has_triangles != 0, sc.needs_uv != 0, sc.has_meshes != 0, sc.has_pass_through != 0, specialised && sc.tables_fit_lds != 0};
     if (!v.cache) v.tris = v.uv = v.pass = true;  // the general kernels
     else if (v.tris) v.pass = v.pass || !v.defer; // scenes with triangles: PASS = false exists for the deferring kernels only
     return v;
@@ -413,17 +445,17 @@ const char* tf(bool v) {
 }
 } // namespace
 
-std::string bounce_kernel_name(const DevScene& sc) {
-    const Variant v = variant_of(sc);
+std::string bounce_kernel_name(const DevScene& sc, bool specialised) {
+    const Variant v = variant_of(sc, specialised);
     return std::string("ptk::k_bounce<") + tf(v.tris) + ", " + tf(v.uv) + ", " + tf(v.defer) + ", " + tf(v.pass) + ", " + tf(v.cache) + ">";
 }
 
-void launch_bounce(hipStream_t s, uint32_t bound, uint32_t rounds, const DevScene& sc, const BatchParams& b, const PathPool& in,
+void launch_bounce(const LaunchContext& lc, uint32_t bound, uint32_t rounds, const DevScene& sc, const BatchParams& b, const PathPool& in,
                    const PathPool& out, const SampleResults& res, const uint32_t* list, const BinInfo* info, uint32_t* block_counts,
                    uint32_t count_stride, unsigned long long* statistics, const DeferQueues& queues) {
+    const hipStream_t s = lc.stream;
     const dim3 grid(min(chunk_blocks(bound, rounds), static_cast<uint32_t>(STATISTICS_SLOTS)));
-    const Variant v = variant_of(sc);
-    if (v.defer) (void) hipMemsetAsync(queues.counters, 0, 4 * sizeof(uint32_t), s);
+    const Variant v = variant_of(sc, lc.specialised);
 #define PTK_CASE(T, U, D, P, C)                                                                                                    \
     if (v.tris == T && v.uv == U && v.defer == D && v.pass == P && v.cache == C)                                                   \
         return launch_bounce_variant<T, U, D, P, C>(s, grid, sc, b, in, out, res, list, info, rounds, block_counts, count_stride, \
@@ -443,11 +475,12 @@ void launch_bounce(hipStream_t s, uint32_t bound, uint32_t rounds, const DevScen
 #undef PTK_CASE
 }
 
-void launch_tail(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
+void launch_tail(const LaunchContext& lc, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
                  const SampleResults& res, const uint32_t* list, BinInfo* info, unsigned long long* statistics) {
+    const hipStream_t s = lc.stream;
     // at most one device fill (two blocks of four waves per CU at two waves per SIMD): the waves are persistent
-    const dim3 grid(min((bound + BLOCK - 1) / BLOCK + 1, 2u * g_compute_units));
-    Variant v = variant_of(sc);
+    const dim3 grid(min((bound + BLOCK - 1) / BLOCK + 1, 2u * lc.compute_units));
+    Variant v = variant_of(sc, lc.specialised);
     if (v.tris) v.pass = true;
 #define PTK_CASE(T, U, P, C)                                            \
     if (v.tris == T && v.uv == U && v.pass == P && v.cache == C)        \
@@ -462,18 +495,20 @@ void launch_tail(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchP
 #undef PTK_CASE
 }
 
-void launch_traverse(hipStream_t s, uint32_t bound, const DevScene& sc, const DeferQueues& queues, unsigned long long* statistics) {
+void launch_traverse(const LaunchContext& lc, uint32_t bound, const DevScene& sc, const DeferQueues& queues, unsigned long long* statistics) {
+    const hipStream_t s = lc.stream;
     // enough blocks to fill the device once (PTK_TRAVERSE_WAVES waves per SIMD, four SIMDs per CU, four waves per block)
-    const uint32_t resident = g_compute_units * PTK_TRAVERSE_WAVES;
+    const uint32_t resident = lc.compute_units * PTK_TRAVERSE_WAVES;
     const dim3 grid(min((2 * bound + BLOCK - 1) / BLOCK + 1, resident));
     hipLaunchKernelGGL(k_traverse, grid, dim3(BLOCK), 0, s, sc, queues, statistics);
 }
 
-void launch_bounce_resume(hipStream_t s, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
+void launch_bounce_resume(const LaunchContext& lc, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
                           const SampleResults& res, uint32_t* block_counts, uint32_t count_stride, unsigned long long* statistics,
                           const DeferQueues& queues) {
+    const hipStream_t s = lc.stream;
     const dim3 grid(min((bound + BLOCK - 1) / BLOCK + 1, static_cast<uint32_t>(STATISTICS_SLOTS)));
-    const Variant v = variant_of(sc);
+    const Variant v = variant_of(sc, lc.specialised);
 #define PTK_CASE(U, P, C)                                 \
     if (v.uv == U && v.pass == P && v.cache == C)         \
         return launch_resume_variant<U, P, C>(s, grid, sc, b, in, out, res, block_counts, count_stride, statistics, queues)

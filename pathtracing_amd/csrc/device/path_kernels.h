@@ -49,8 +49,9 @@ constexpr int BLOCK = 256;
 #define PTK_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 static_assert(BLOCK == BIN_BLOCK, "k_extend and the bin kernels share their block geometry");
 
-PTK_DEV TraversalStack make_stack(StackEntry* lds, StackEntry* spill) {
+PTK_DEV TraversalStack make_stack(StackEntry* lds, StackEntry* spill, uint32_t* overflows) {
     TraversalStack st;
+    st.overflows = overflows;
     st.lds = (LdsStackEntry*) lds + threadIdx.x;
     st.stride = blockDim.x;
     st.spill = spill;
@@ -58,10 +59,10 @@ PTK_DEV TraversalStack make_stack(StackEntry* lds, StackEntry* spill) {
     st.nodes_visited = st.triangles_tested = 0;
     return st;
 }
-// declares the traversal stack `st` of a kernel over its LDS array
-#define PTK_TRAVERSAL_STACK(st, lds_array)        \
+// declares the traversal stack `st` of a kernel over its LDS array; `scene` is the kernel's DevScene argument
+#define PTK_TRAVERSAL_STACK(st, lds_array, scene) \
     StackEntry st##_spill[SPILL_STACK_DEPTH];     \
-    TraversalStack st = make_stack(lds_array, st##_spill)
+    TraversalStack st = make_stack(lds_array, st##_spill, (scene).stack_overflows)
 
 PTK_DEV void sample_coordinates(const BatchParams& b, uint32_t sid, uint32_t& pixel, uint32_t& sample) {
     uint32_t s = sid / b.n_pixels;
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, 
                                                     uint32_t* block_counts, uint32_t count_stride) {
     __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1];
     __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
-    PTK_TRAVERSAL_STACK(st, lds_stack);
+    PTK_TRAVERSAL_STACK(st, lds_stack, sc);
     if (blockIdx.x == 0 && threadIdx.x < N_CLASSES) {
         first_info->start[threadIdx.x] = threadIdx.x == 0 ? 0u : b.n_paths;
         first_info->count[threadIdx.x] = threadIdx.x == 0 ? b.n_paths : 0u;
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
     __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
     __shared__ uint32_t queue_counts[BLOCK / 64][2];
     __shared__ uint32_t queue_base[2];
-    PTK_TRAVERSAL_STACK(st, lds_stack);
+    PTK_TRAVERSAL_STACK(st, lds_stack, sc_global);
     __shared__ double lds_scene[CACHE ? LDS_SCENE_DOUBLES : 1];
     const DevScene sc = stage_scene<CACHE>(sc_global, lds_scene);
     const ChunkTable table = chunk_table(info, rounds * BLOCK);
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
                                                                                     BinInfo* info, unsigned long long* statistics) {
     __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1];
     __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
-    PTK_TRAVERSAL_STACK(st, lds_stack);
+    PTK_TRAVERSAL_STACK(st, lds_stack, sc_global);
     const uint32_t n = info->total;
     __shared__ double lds_scene[CACHE ? LDS_SCENE_DOUBLES : 1];
     const DevScene sc = stage_scene<CACHE>(sc_global, lds_scene);
@@ -891,7 +892,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
                                                                                              DeferQueues queues) {
     __shared__ StackEntry lds_stack[PASS ? LDS_STACK_DEPTH * BLOCK : 1];
     __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
-    PTK_TRAVERSAL_STACK(st, lds_stack);
+    PTK_TRAVERSAL_STACK(st, lds_stack, sc_global);
     const uint32_t n = queues.counters[1];
     if (blockIdx.x * BLOCK >= n) return;
     __shared__ double lds_scene[CACHE ? LDS_SCENE_DOUBLES : 1];

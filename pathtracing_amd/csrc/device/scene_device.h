@@ -156,6 +156,7 @@ struct DevScene {
     int32_t n_meshes, _pad2;
     uint32_t class_mask;                 // material classes present in the scene (+ scatter bit)
     float mesh_bound_abs;                // largest absolute coordinate of any mesh's bounds, rounded up
+    uint32_t* stack_overflows;           // one counter: pushes a full traversal stack had to drop (TraversalStack::push)
 };
 
 // LDS every block of the shading kernels sets aside for copies of the object, light and medium tables

@@ -44,6 +44,7 @@ struct Builder {
     std::vector<Node2>& nodes;
     std::atomic<int32_t>& next_node;
     int max_leaf, n_bins;
+    int sah_depth_cap; // below this depth splits follow the surface-area heuristic, from it on they halve the range
 
     int32_t build(uint32_t first, uint32_t count, int depth, int parallel_levels) {
         const int32_t id = next_node.fetch_add(1);
@@ -68,7 +69,7 @@ struct Builder {
         }
         uint32_t mid = first + count / 2;
         bool split_done = false;
-        if (extent > 0 && depth < 56) {
+        if (extent > 0 && depth < sah_depth_cap) {
             const int B = n_bins;
             std::vector<Box> bin_box(static_cast<size_t>(B));
             std::vector<uint32_t> bin_count(static_cast<size_t>(B), 0);
@@ -147,26 +148,36 @@ float round_up(double v) {
 struct Collapser {
     const std::vector<Node2>& n2;
     std::vector<BvhNode4>& out;
+    bool level_order; // open the children of a node level by level instead of by surface area
     int max_depth = 0;
 
     int32_t encode_leaf(const Node2& n) const {
         return ~static_cast<int32_t>(n.first * 8u + (n.count - 1u));
     }
 
-    int32_t emit(int32_t id, int depth) {
+    // Emits the 4-wide node for binary node `id` and its subtree.  stack_need: the most entries the ordered walk
+    // (visit_inner in device/geometry.h) can hold while it is inside this subtree: a node pushes every child but
+    // the one it descends into.
+    int32_t emit(int32_t id, int depth, int& stack_need) {
         max_depth = std::max(max_depth, depth);
         const int32_t me = static_cast<int32_t>(out.size());
         out.emplace_back();
         int32_t kids[4];
+        int level[4]; // binary levels below `id`
         int nk = 0;
-        kids[nk++] = n2[static_cast<size_t>(id)].left;
-        kids[nk++] = n2[static_cast<size_t>(id)].right;
-        while (nk < 4) { // open the inner child with the largest surface area
+        kids[nk] = n2[static_cast<size_t>(id)].left;
+        level[nk++] = 1;
+        kids[nk] = n2[static_cast<size_t>(id)].right;
+        level[nk++] = 1;
+        while (nk < 4) { // open the inner child with the largest surface area (level_order: the shallowest first)
             int pick = -1;
             double area = -1;
             for (int i = 0; i < nk; i++) {
                 const Node2& c = n2[static_cast<size_t>(kids[i])];
-                if (c.left >= 0 && c.box.half_area() > area) {
+                if (c.left < 0) continue;
+                const bool better = pick < 0 || (level_order && level[i] < level[pick]) ||
+                                    ((!level_order || level[i] == level[pick]) && c.box.half_area() > area);
+                if (better) {
                     area = c.box.half_area();
                     pick = i;
                 }
@@ -174,7 +185,9 @@ struct Collapser {
             if (pick < 0) break;
             const Node2& c = n2[static_cast<size_t>(kids[pick])];
             kids[pick] = c.left;
-            kids[nk++] = c.right;
+            level[pick]++;
+            kids[nk] = c.right;
+            level[nk++] = level[pick];
         }
         BvhNode4 node{};
         for (int i = 0; i < 4; i++) {
@@ -193,42 +206,24 @@ struct Collapser {
             node.hi_z[i] = round_up(c.box.hi[2] + EPSILON);
         }
         out[static_cast<size_t>(me)] = node;
+        int below = 0;
         for (int i = 0; i < nk; i++) {
             const Node2& c = n2[static_cast<size_t>(kids[i])];
-            int32_t ref = c.left >= 0 ? emit(kids[i], depth + 1) : encode_leaf(c);
+            int need = 0;
+            int32_t ref = c.left >= 0 ? emit(kids[i], depth + 1, need) : encode_leaf(c);
+            below = std::max(below, need);
             out[static_cast<size_t>(me)].child[i] = ref;
         }
+        stack_need = nk - 1 + below;
         return me;
     }
 };
 
 } // namespace
 
-BuiltBvh build_bvh4(const double* vertices, int64_t n, int max_leaf, int n_bins, int threads) {
-    BuiltBvh result;
-    if (n <= 0) return result;
-    max_leaf = std::min(std::max(max_leaf, 1), 8);
-    n_bins = std::min(std::max(n_bins, 2), 64);
-    std::vector<Box> boxes(static_cast<size_t>(n));
-    std::vector<double> centroids(static_cast<size_t>(n) * 3);
-    for (int64_t i = 0; i < n; i++) {
-        const double* p = vertices + 9 * i;
-        Box b;
-        b.grow(p);
-        b.grow(p + 3);
-        b.grow(p + 6);
-        boxes[static_cast<size_t>(i)] = b;
-        for (int a = 0; a < 3; a++) centroids[3 * static_cast<size_t>(i) + a] = (p[a] + p[3 + a] + p[6 + a]) / 3.0;
-    }
-    result.order.resize(static_cast<size_t>(n));
-    for (int64_t i = 0; i < n; i++) result.order[static_cast<size_t>(i)] = static_cast<uint32_t>(i);
-    std::vector<Node2> nodes(static_cast<size_t>(2 * n));
-    std::atomic<int32_t> next_node{0};
-    Builder builder{boxes, centroids, result.order, nodes, next_node, max_leaf, n_bins};
-    int levels = 0;
-    while ((1 << levels) < threads) levels++;
-    int32_t root = builder.build(0, static_cast<uint32_t>(n), 0, levels);
-
+// Binary tree -> 4-wide nodes in result.nodes, with the tree's depth and stack need.
+static void build_wide(const std::vector<Node2>& nodes, int32_t root, bool level_order, BuiltBvh& result) {
+    result.nodes.clear();
     if (nodes[static_cast<size_t>(root)].left < 0) { // the whole mesh fits one leaf: root with a single leaf child
         BvhNode4 node{};
         const Node2& c = nodes[static_cast<size_t>(root)];
@@ -246,12 +241,53 @@ BuiltBvh build_bvh4(const double* vertices, int64_t n, int max_leaf, int n_bins,
         node.child[0] = ~static_cast<int32_t>(c.first * 8u + (c.count - 1u));
         result.nodes.push_back(node);
         result.max_depth = 1;
-        return result;
+        result.max_stack = 0;
+        return;
     }
-    result.nodes.reserve(static_cast<size_t>(n));
-    Collapser collapser{nodes, result.nodes};
-    collapser.emit(root, 1);
+    result.nodes.reserve(nodes.size() / 2);
+    Collapser collapser{nodes, result.nodes, level_order};
+    int need = 0;
+    collapser.emit(root, 1, need);
     result.max_depth = collapser.max_depth;
+    result.max_stack = need;
+}
+
+BuiltBvh build_bvh4(const double* vertices, int64_t n, int max_leaf, int n_bins, int threads, int stack_limit) {
+    BuiltBvh result;
+    if (n <= 0) return result;
+    max_leaf = std::min(std::max(max_leaf, 1), 8);
+    n_bins = std::min(std::max(n_bins, 2), 64);
+    std::vector<Box> boxes(static_cast<size_t>(n));
+    std::vector<double> centroids(static_cast<size_t>(n) * 3);
+    for (int64_t i = 0; i < n; i++) {
+        const double* p = vertices + 9 * i;
+        Box b;
+        b.grow(p);
+        b.grow(p + 3);
+        b.grow(p + 6);
+        boxes[static_cast<size_t>(i)] = b;
+        for (int a = 0; a < 3; a++) centroids[3 * static_cast<size_t>(i) + a] = (p[a] + p[3 + a] + p[6 + a]) / 3.0;
+    }
+    result.order.resize(static_cast<size_t>(n));
+    std::vector<Node2> nodes(static_cast<size_t>(2 * n));
+    int levels = 0;
+    while ((1 << levels) < threads) levels++;
+    // The walk's stack is finite, so the tree must not need more of it than `stack_limit` entries.  Triangles spread
+    // evenly (every mesh seen so far) stay far below it; for a mesh the heuristic turns into a deep, lopsided tree the
+    // build is repeated with the heuristic confined to fewer top levels, and at last with none: splitting every range
+    // in halves and opening children level by level gives a 4-wide tree of depth ceil(log2(n) / 2) <= 14 that
+    // needs at most 42 entries.
+    const int caps[] = {56, 24, 12, 0};
+    for (int attempt = 0; attempt < 4; attempt++) {
+        for (int64_t i = 0; i < n; i++) result.order[static_cast<size_t>(i)] = static_cast<uint32_t>(i);
+        std::fill(nodes.begin(), nodes.end(), Node2{});
+        std::atomic<int32_t> next_node{0};
+        Builder builder{boxes, centroids, result.order, nodes, next_node, max_leaf, n_bins, caps[attempt]};
+        const int32_t root = builder.build(0, static_cast<uint32_t>(n), 0, levels);
+        result.sah_depth_cap = caps[attempt];
+        build_wide(nodes, root, caps[attempt] == 0, result);
+        if (result.max_stack <= stack_limit) break;
+    }
     return result;
 }
 

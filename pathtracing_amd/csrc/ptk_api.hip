@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -10,6 +11,8 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -23,11 +26,27 @@ using namespace ptk;
 namespace {
 
 thread_local std::string g_error;
-hipStream_t g_stream = nullptr;
-int g_device = -1;
-bool g_profiling = false;
+
+// One context per device the process has initialised (ptk_init): the library's stream on that device and what the
+// launchers need to know about it.  Scenes and films remember the context they were created in, so one process can
+// drive several GPUs, one host thread per GPU; calls without a scene or film argument use the device the calling thread
+// selected with its last ptk_init (or, for a thread that never called it, the process's most recent one).
+struct DeviceContext {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    uint32_t compute_units = 256;
+};
+constexpr int MAX_DEVICES = 64;
+DeviceContext g_contexts[MAX_DEVICES];
+std::mutex g_context_mutex;
+std::atomic<int> g_default_device{-1};
+thread_local int t_device = -1;
+
+// Process-wide tuning knobs (ptk_set_option, ptk_set_profiling): read at every batch; results do not depend on them.
+std::atomic<bool> g_profiling{false};
 constexpr uint32_t TAIL_RECORDS_LIMIT = 1u << 24; // upper limit of the tail_records option (no batch is larger)
-uint32_t g_tail_records = TAIL_RECORDS;
+std::atomic<uint32_t> g_tail_records{TAIL_RECORDS};
+std::atomic<bool> g_specialised{true};
 
 int fail(int code, const std::string& message) {
     g_error = message;
@@ -41,10 +60,36 @@ int fail(int code, const std::string& message) {
             return fail(PTK_ERR_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(e_));          \
     } while (0)
 
-int require_init() {
-    if (g_device < 0) return fail(PTK_ERR_DEVICE, "ptk_init() has not been called (or no GPU is available)");
+// The calling thread's context, made current; nullptr (and the error message set) before any ptk_init.
+DeviceContext* current_context() {
+    const int device = t_device >= 0 ? t_device : g_default_device.load();
+    if (device < 0) {
+        fail(PTK_ERR_DEVICE, "ptk_init() has not been called (or no GPU is available)");
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        fail(PTK_ERR_DEVICE, "hipSetDevice failed for the device selected by ptk_init");
+        return nullptr;
+    }
+    return &g_contexts[device];
+}
+// Makes the device of a scene's or film's context current for the calling thread.
+int use(const DeviceContext* ctx) {
+    if (!ctx) return fail(PTK_ERR_INVALID, "object without a device context");
+    HIP_TRY(hipSetDevice(ctx->device));
     return PTK_OK;
 }
+LaunchContext launch_context(const DeviceContext* ctx) {
+    return LaunchContext{ctx->stream, ctx->compute_units, g_specialised.load()};
+}
+
+// Exceptions never cross the C boundary: the bodies of the entry points that allocate or parse run inside these.
+#define PTK_GUARD_BEGIN try {
+#define PTK_GUARD_END                                                                    \
+    }                                                                                    \
+    catch (const std::bad_alloc&) { return fail(PTK_ERR_MEMORY, "out of host memory"); } \
+    catch (const std::exception& e) { return fail(PTK_ERR_INVALID, std::string("unexpected error: ") + e.what()); } \
+    catch (...) { return fail(PTK_ERR_INVALID, "unexpected error"); }
 
 // ---- host double[3] helpers in the reference's operation order ---------------------------------
 struct H3 {
@@ -153,6 +198,7 @@ constexpr int INFO_RING = 8;
 } // namespace
 
 struct PtkFilm {
+    DeviceContext* ctx = nullptr;
     int32_t width = 0, height = 0;
     bool owns_buffers = true;
     double *image = nullptr, *position = nullptr, *normal = nullptr;
@@ -160,6 +206,7 @@ struct PtkFilm {
 };
 
 struct PtkScene {
+    DeviceContext* ctx = nullptr;
     DevScene dev{};
     PtkSettings settings{};
     DeviceBuffers scene_buffers; // tables, triangles, nodes
@@ -174,13 +221,24 @@ struct PtkScene {
     BinInfo* d_info = nullptr;  // [2]: summaries of the previous and the current bounce's lists
     BinInfo* h_info = nullptr;  // pinned ring of INFO_RING summaries read back asynchronously
     hipEvent_t info_events[8] = {};
-    unsigned long long* h_rays = nullptr; // pinned [2][N_STATISTICS]
+    unsigned long long* h_rays = nullptr; // pinned [2][N_STATISTICS], then the stack-overflow counter (32 bits used)
     unsigned long long* d_statistics = nullptr; // STATISTICS_SLOTS per-block slots, then the totals
     DeferQueues queues{};       // scenes with meshes: rays and vertices waiting for k_traverse / k_bounce_resume
     std::vector<int> classes; // queue classes present in the scene
     PtkFilm* host_film = nullptr; // scratch film for ptk_render_host
     PtkStats stats{};
     std::vector<hipEvent_t> events;
+    PtkScene() = default;
+    PtkScene(const PtkScene&) = delete;
+    PtkScene& operator=(const PtkScene&) = delete;
+    ~PtkScene() { // the device buffers go with their DeviceBuffers members
+        if (h_info) (void) hipHostFree(h_info);
+        if (h_rays) (void) hipHostFree(h_rays);
+        for (hipEvent_t e : info_events)
+            if (e) (void) hipEventDestroy(e);
+        for (hipEvent_t e : events) (void) hipEventDestroy(e);
+        if (host_film) ptk_film_destroy(host_film);
+    }
 };
 
 namespace {
@@ -230,6 +288,7 @@ constexpr size_t STATISTICS_BYTES = STATISTICS_VALUES * sizeof(unsigned long lon
 
 struct EventTimer {
     PtkScene* s;
+    bool on; // profiling as it was set when the batch began
     size_t next = 0;
     std::vector<std::pair<int, std::pair<size_t, size_t>>> spans; // family, (begin, end)
     hipEvent_t get() {
@@ -241,20 +300,20 @@ struct EventTimer {
         return s->events[next++];
     }
     void begin(int family) {
-        if (!g_profiling) return;
+        if (!on) return;
         hipEvent_t e = get();
-        (void) hipEventRecord(e, g_stream);
+        (void) hipEventRecord(e, s->ctx->stream);
         spans.push_back({family, {next - 1, 0}});
     }
     void end() {
-        if (!g_profiling) return;
+        if (!on) return;
         hipEvent_t e = get();
-        (void) hipEventRecord(e, g_stream);
+        (void) hipEventRecord(e, s->ctx->stream);
         spans.back().second.second = next - 1;
     }
     void collect() {
-        if (!g_profiling) return;
-        (void) hipStreamSynchronize(g_stream);
+        if (!on) return;
+        (void) hipStreamSynchronize(s->ctx->stream);
         for (auto& sp : spans) {
             float ms = 0;
             (void) hipEventElapsedTime(&ms, s->events[sp.second.first], s->events[sp.second.second]);
@@ -277,8 +336,11 @@ struct EventTimer {
 // memory, grids are sized by the newest count the host has seen (counts only shrink), and the
 // per-bounce summaries come back through a ring of pinned slots that is polled, not waited on.
 int trace_batch(PtkScene* s, const BatchParams& b) {
-    EventTimer timer{s};
+    EventTimer timer{s, g_profiling.load()};
     PtkStats& st = s->stats;
+    const LaunchContext lc = launch_context(s->ctx);
+    const hipStream_t g_stream = lc.stream; // the stream of the scene's device
+    const uint32_t tail_records = g_tail_records.load();
     HIP_TRY(hipMemsetAsync(s->d_statistics, 0, STATISTICS_BYTES, g_stream));
     timer.begin(2);
     launch_generate(g_stream, s->dev, b, s->pools[0], s->results, &s->d_info[1], s->block_counts, s->count_stride);
@@ -324,10 +386,10 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
         timer.begin(1);
         launch_bin(g_stream, s->dev, current, bound, pool_rounds, previous, s->block_counts, s->count_stride, info, s->list);
         timer.end();
-        const uint64_t tail_at = s->dev.has_meshes ? 4ull * g_tail_records : g_tail_records;
+        const uint64_t tail_at = s->dev.has_meshes ? 4ull * tail_records : tail_records;
         if (bound <= tail_at) { // few paths left: one launch follows every one of them to its end
             timer.begin(0);
-            launch_tail(g_stream, bound, s->dev, b, current, next, s->results, s->list, info, s->d_statistics);
+            launch_tail(lc, bound, s->dev, b, current, next, s->results, s->list, info, s->d_statistics);
             timer.end();
             const int slot = launched % INFO_RING;
             HIP_TRY(hipMemcpyAsync(&s->h_info[slot], info, sizeof(BinInfo), hipMemcpyDeviceToHost, g_stream));
@@ -340,15 +402,16 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
         }
         timer.begin(0);
         pool_rounds = chunk_rounds(bound);
-        launch_bounce(g_stream, bound, pool_rounds, s->dev, b, current, next, s->results, s->list, info, s->block_counts,
+        if (s->dev.has_meshes) HIP_TRY(hipMemsetAsync(s->queues.counters, 0, 4 * sizeof(uint32_t), g_stream));
+        launch_bounce(lc, bound, pool_rounds, s->dev, b, current, next, s->results, s->list, info, s->block_counts,
                       s->count_stride, s->d_statistics, s->queues);
         timer.end();
         if (s->dev.has_meshes) { // finish what misses every mesh above, walk the hierarchies, finish the rest
             timer.begin(3);
-            launch_traverse(g_stream, bound, s->dev, s->queues, s->d_statistics + STATISTICS_SET);
+            launch_traverse(lc, bound, s->dev, s->queues, s->d_statistics + STATISTICS_SET);
             timer.end();
             timer.begin(0);
-            launch_bounce_resume(g_stream, bound, s->dev, b, current, next, s->results, s->block_counts, s->count_stride, s->d_statistics,
+            launch_bounce_resume(lc, bound, s->dev, b, current, next, s->results, s->block_counts, s->count_stride, s->d_statistics,
                                  s->queues);
             timer.end();
             st.traverse_launches++;
@@ -365,6 +428,7 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
     launch_sum_statistics(g_stream, s->d_statistics, totals);
     if (s->dev.has_meshes) launch_sum_statistics(g_stream, s->d_statistics + STATISTICS_SET, totals + N_STATISTICS);
     HIP_TRY(hipMemcpyAsync(s->h_rays, totals, 2 * N_STATISTICS * sizeof(unsigned long long), hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(s->h_rays + 2 * N_STATISTICS, s->dev.stack_overflows, sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
     int rc = retire(true);
     if (rc != PTK_OK) return rc;
     HIP_TRY(hipStreamSynchronize(g_stream));
@@ -386,6 +450,7 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
         st.traverse_bytes += tb;
         st.algorithmic_bytes += tb;
     }
+    st.stack_overflows = s->h_rays[2 * N_STATISTICS]; // counted since the scene was created
     st.shadow_rays += segments;
     st.extension_rays += extensions;
     st.vertices += sum_vertices;
@@ -442,26 +507,30 @@ const char* ptk_last_error(void) {
 }
 
 int ptk_init(int device) {
+    PTK_GUARD_BEGIN
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0)
         return fail(PTK_ERR_DEVICE, "no HIP device available: this library has no CPU path");
-    if (device < 0 || device >= count) return fail(PTK_ERR_INVALID, "ptk_init: device index out of range");
+    if (device < 0 || device >= count || device >= MAX_DEVICES) return fail(PTK_ERR_INVALID, "ptk_init: device index out of range");
     HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(PTK_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", but the kernels are built for gfx950 only");
-    set_compute_units(prop.multiProcessorCount);
-    if (g_stream && g_device != device) {
-        (void) hipStreamDestroy(g_stream);
-        g_stream = nullptr;
+    std::lock_guard<std::mutex> lock(g_context_mutex);
+    DeviceContext& ctx = g_contexts[device];
+    if (ctx.device < 0) { // first use of this device: its stream lives until the process ends
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(PTK_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", but the kernels are built for gfx950 only");
+        if (prop.multiProcessorCount > 0) ctx.compute_units = static_cast<uint32_t>(prop.multiProcessorCount);
+        HIP_TRY(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+        ctx.device = device;
     }
-    if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-    g_device = device;
+    t_device = device;
+    g_default_device = device;
     const char* prof = std::getenv("PTK_PROFILE");
     if (prof && prof[0] == '1') g_profiling = true;
     return PTK_OK;
+    PTK_GUARD_END
 }
 
 int ptk_set_option(const char* name, int64_t value) {
@@ -473,7 +542,7 @@ int ptk_set_option(const char* name, int64_t value) {
     }
     if (name && std::strcmp(name, "specialised_kernels") == 0) {
         if (value != 0 && value != 1) return fail(PTK_ERR_INVALID, "ptk_set_option: specialised_kernels must be 0 or 1");
-        set_specialised_kernels(value != 0);
+        g_specialised = value != 0;
         return PTK_OK;
     }
     return fail(PTK_ERR_INVALID, std::string("ptk_set_option: unknown option ") + (name ? name : "(null)"));
@@ -485,19 +554,23 @@ int ptk_set_profiling(int enabled) {
 }
 
 int ptk_sync(void) {
-    if (require_init() != PTK_OK) return PTK_ERR_DEVICE;
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    DeviceContext* ctx = current_context();
+    if (!ctx) return PTK_ERR_DEVICE;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PTK_OK;
 }
 
 void* ptk_stream(void) {
-    return g_stream;
+    DeviceContext* ctx = current_context();
+    return ctx ? ctx->stream : nullptr;
 }
 
 int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScene** out) {
     if (!d || !out) return fail(PTK_ERR_INVALID, "ptk_scene_create: null argument");
     *out = nullptr;
-    if (require_init() != PTK_OK) return PTK_ERR_DEVICE;
+    DeviceContext* ctx = current_context();
+    if (!ctx) return PTK_ERR_DEVICE;
+    PTK_GUARD_BEGIN
     if (d->settings.width < 1 || d->settings.height < 1) return fail(PTK_ERR_INVALID, "ptk_scene_create: empty image");
     if (static_cast<int64_t>(d->settings.width) * d->settings.height > (int64_t(1) << 31))
         return fail(PTK_ERR_INVALID, "ptk_scene_create: image larger than 2^31 pixels");
@@ -507,9 +580,19 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
         return fail(PTK_ERR_INVALID, "ptk_scene_create: max_recursion_depth must be in [0, 8000]");
     if (d->background_medium < 0 || d->background_medium >= d->n_media)
         return fail(PTK_ERR_INVALID, "ptk_scene_create: background_medium out of range");
-    if (d->n_triangles > (int64_t(1) << 28)) return fail(PTK_ERR_INVALID, "ptk_scene_create: at most 2^28 triangles");
+    if (d->n_triangles < 0 || d->n_triangles > (int64_t(1) << 28)) return fail(PTK_ERR_INVALID, "ptk_scene_create: between 0 and 2^28 triangles");
+    if (d->n_materials < 0 || d->n_materials > 65535 || d->n_maps < 0 || d->n_maps > (1 << 24) || d->n_map_values < 0)
+        return fail(PTK_ERR_INVALID, "ptk_scene_create: negative or excessive table size");
+    if ((d->n_objects > 0 && !d->objects) || (d->n_materials > 0 && !d->materials) || !d->media || (d->n_maps > 0 && !d->maps) ||
+        (d->n_map_values > 0 && !d->map_data))
+        return fail(PTK_ERR_INVALID, "ptk_scene_create: a table with a positive size has a null pointer");
+    if (d->n_triangles > 0 && (!d->tri_vertices || !d->tri_uv || !d->tri_normals || !d->tri_flags))
+        return fail(PTK_ERR_INVALID, "ptk_scene_create: the triangle arrays (vertices, uv, normals, flags) must all be present");
+    if (d->settings.bvh_leaf_size < 1 || d->settings.bvh_n_axis_splits < 1)
+        return fail(PTK_ERR_INVALID, "ptk_scene_create: bvh_leaf_size and bvh_n_axis_splits must be at least 1");
 
     std::unique_ptr<PtkScene> s(new PtkScene());
+    s->ctx = ctx;
     s->settings = d->settings;
     // records are addressed with 32-bit byte offsets (160 bytes each): at most 2^24 in flight; larger jobs are
     // cut into batches anyway
@@ -664,9 +747,11 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
                 const double* verts = d->tri_vertices + 9 * po.first_triangle;
                 // bvh_leaf_size tunes the reference's tree for its cost balance; here an exact fp64 triangle test costs
                 // about as much as a 4-wide node, so leaves hold at most two triangles (measured: +6 % over four)
-                BuiltBvh bvh = build_bvh4(verts, n, std::min(d->settings.bvh_leaf_size, 2), d->settings.bvh_n_axis_splits, build_threads);
-                if (3 * bvh.max_depth + 1 > LDS_STACK_DEPTH + SPILL_STACK_DEPTH)
-                    return fail(PTK_ERR_MEMORY, "ptk_scene_create: mesh hierarchy deeper than the traversal stack allows");
+                BuiltBvh bvh = build_bvh4(verts, n, std::min(d->settings.bvh_leaf_size, 2), d->settings.bvh_n_axis_splits, build_threads,
+                                          LDS_STACK_DEPTH + SPILL_STACK_DEPTH);
+                // backstop: the builder bounds the stack its tree needs (build_bvh4), so this cannot fail
+                if (bvh.max_stack > LDS_STACK_DEPTH + SPILL_STACK_DEPTH)
+                    return fail(PTK_ERR_MEMORY, "ptk_scene_create: mesh hierarchy needs a deeper traversal stack than the kernels have");
                 std::vector<int32_t> leaf_position(static_cast<size_t>(n)); // face -> position in leaf order
                 for (int64_t k = 0; k < n; k++) leaf_position[bvh.order[static_cast<size_t>(k)]] = static_cast<int32_t>(k);
                 const size_t base = tri_hot.size();
@@ -872,28 +957,29 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     HIP_TRY(buf.alloc(&s->d_info, 2));
     HIP_TRY(buf.alloc(&s->d_statistics, STATISTICS_VALUES));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_info), INFO_RING * sizeof(BinInfo), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_rays), 2 * N_STATISTICS * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_rays), (2 * N_STATISTICS + 1) * sizeof(unsigned long long), hipHostMallocDefault));
+    s->h_rays[2 * N_STATISTICS] = 0;
+    HIP_TRY(buf.alloc(&dev.stack_overflows, 1));
+    HIP_TRY(hipMemset(dev.stack_overflows, 0, sizeof(uint32_t)));
     for (int i = 0; i < INFO_RING; i++) HIP_TRY(hipEventCreateWithFlags(&s->info_events[i], hipEventDisableTiming));
     *out = s.release();
     return PTK_OK;
+    PTK_GUARD_END
 }
 
 void ptk_scene_destroy(PtkScene* scene) {
     if (!scene) return;
-    if (g_stream) (void) hipStreamSynchronize(g_stream);
-    if (scene->h_info) (void) hipHostFree(scene->h_info);
-    if (scene->h_rays) (void) hipHostFree(scene->h_rays);
-    for (hipEvent_t e : scene->info_events)
-        if (e) (void) hipEventDestroy(e);
-    for (hipEvent_t e : scene->events) (void) hipEventDestroy(e);
-    if (scene->host_film) ptk_film_destroy(scene->host_film);
+    if (scene->ctx && hipSetDevice(scene->ctx->device) == hipSuccess) (void) hipStreamSynchronize(scene->ctx->stream);
     delete scene;
 }
 
 int ptk_trace_primary(PtkScene* s, const PtkRenderJob* job, int32_t* object_index, int32_t* primitive_index, double* distance,
                       double* position, double* normal) {
+    PTK_GUARD_BEGIN
     int rc = check_job(s, job, "ptk_trace_primary");
     if (rc != PTK_OK) return rc;
+    if ((rc = use(s->ctx)) != PTK_OK) return rc;
+    const hipStream_t g_stream = s->ctx->stream;
     const size_t n = static_cast<size_t>(job->number_of_pixels);
     if (n == 0) return PTK_OK;
     DeviceBuffers tmp;
@@ -920,11 +1006,15 @@ int ptk_trace_primary(PtkScene* s, const PtkRenderJob* job, int32_t* object_inde
     if (position) HIP_TRY(hipMemcpy(position, d_pos, n * 24, hipMemcpyDeviceToHost));
     if (normal) HIP_TRY(hipMemcpy(normal, d_nrm, n * 24, hipMemcpyDeviceToHost));
     return PTK_OK;
+    PTK_GUARD_END
 }
 
 int ptk_trace_samples(PtkScene* s, const PtkRenderJob* job, double* color, double* position, double* normal) {
+    PTK_GUARD_BEGIN
     int rc = check_job(s, job, "ptk_trace_samples");
     if (rc != PTK_OK) return rc;
+    if ((rc = use(s->ctx)) != PTK_OK) return rc;
+    const hipStream_t g_stream = s->ctx->stream;
     const size_t total = static_cast<size_t>(job->number_of_pixels) * static_cast<size_t>(job->number_of_samples) * 3;
     if (total == 0) return PTK_OK;
     DeviceBuffers tmp;
@@ -943,36 +1033,50 @@ int ptk_trace_samples(PtkScene* s, const PtkRenderJob* job, double* color, doubl
     if (position) HIP_TRY(hipMemcpy(position, d_pos, total * 8, hipMemcpyDeviceToHost));
     if (normal) HIP_TRY(hipMemcpy(normal, d_nrm, total * 8, hipMemcpyDeviceToHost));
     return PTK_OK;
+    PTK_GUARD_END
+}
+
+static int film_create(DeviceContext* ctx, int32_t width, int32_t height, PtkFilm** out) {
+    PTK_GUARD_BEGIN
+    std::unique_ptr<PtkFilm> f(new PtkFilm());
+    f->ctx = ctx;
+    f->width = width;
+    f->height = height;
+    const size_t n = static_cast<size_t>(width) * static_cast<size_t>(height);
+    PtkFilm* film = f.release(); // from here on ptk_film_destroy frees whatever has been allocated
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&film->image), n * 24);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&film->position), n * 24);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&film->normal), n * 24);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&film->counters), n * 8);
+    int rc = e == hipSuccess ? ptk_film_clear(film) : fail(PTK_ERR_MEMORY, std::string("ptk_film_create: ") + hipGetErrorString(e));
+    if (rc != PTK_OK) {
+        const std::string message = g_error;
+        ptk_film_destroy(film);
+        g_error = message;
+        return rc;
+    }
+    *out = film;
+    return PTK_OK;
+    PTK_GUARD_END
 }
 
 int ptk_film_create(int32_t width, int32_t height, PtkFilm** out) {
     if (!out || width < 1 || height < 1) return fail(PTK_ERR_INVALID, "ptk_film_create: bad argument");
     *out = nullptr;
-    if (require_init() != PTK_OK) return PTK_ERR_DEVICE;
-    std::unique_ptr<PtkFilm> f(new PtkFilm());
-    f->width = width;
-    f->height = height;
-    const size_t n = static_cast<size_t>(width) * static_cast<size_t>(height);
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f->image), n * 24));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f->position), n * 24));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f->normal), n * 24));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f->counters), n * 8));
-    PtkFilm* film = f.release();
-    int rc = ptk_film_clear(film);
-    if (rc != PTK_OK) {
-        ptk_film_destroy(film);
-        return rc;
-    }
-    *out = film;
-    return PTK_OK;
+    DeviceContext* ctx = current_context();
+    if (!ctx) return PTK_ERR_DEVICE;
+    return film_create(ctx, width, height, out);
 }
 
 int ptk_film_wrap(int32_t width, int32_t height, double* d_image, double* d_position, double* d_normal, uint64_t* d_counters,
                   PtkFilm** out) {
     if (!out || width < 1 || height < 1 || !d_image || !d_position || !d_normal || !d_counters)
         return fail(PTK_ERR_INVALID, "ptk_film_wrap: bad argument");
-    if (require_init() != PTK_OK) return PTK_ERR_DEVICE;
-    PtkFilm* f = new PtkFilm();
+    DeviceContext* ctx = current_context();
+    if (!ctx) return PTK_ERR_DEVICE;
+    PtkFilm* f = new (std::nothrow) PtkFilm();
+    if (!f) return fail(PTK_ERR_MEMORY, "out of host memory");
+    f->ctx = ctx;
     f->width = width;
     f->height = height;
     f->owns_buffers = false;
@@ -986,7 +1090,7 @@ int ptk_film_wrap(int32_t width, int32_t height, double* d_image, double* d_posi
 
 void ptk_film_destroy(PtkFilm* f) {
     if (!f) return;
-    if (g_stream) (void) hipStreamSynchronize(g_stream);
+    if (f->ctx && hipSetDevice(f->ctx->device) == hipSuccess) (void) hipStreamSynchronize(f->ctx->stream);
     if (f->owns_buffers) {
         (void) hipFree(f->image);
         (void) hipFree(f->position);
@@ -998,6 +1102,8 @@ void ptk_film_destroy(PtkFilm* f) {
 
 int ptk_film_clear(PtkFilm* f) {
     if (!f) return fail(PTK_ERR_INVALID, "ptk_film_clear: null film");
+    if (use(f->ctx) != PTK_OK) return PTK_ERR_DEVICE;
+    const hipStream_t g_stream = f->ctx->stream;
     const size_t n = static_cast<size_t>(f->width) * static_cast<size_t>(f->height);
     HIP_TRY(hipMemsetAsync(f->image, 0, n * 24, g_stream));
     HIP_TRY(hipMemsetAsync(f->position, 0, n * 24, g_stream));
@@ -1008,6 +1114,8 @@ int ptk_film_clear(PtkFilm* f) {
 
 int ptk_film_upload(PtkFilm* f, const double* image, const double* position, const double* normal, const uint64_t* counters) {
     if (!f) return fail(PTK_ERR_INVALID, "ptk_film_upload: null film");
+    if (use(f->ctx) != PTK_OK) return PTK_ERR_DEVICE;
+    const hipStream_t g_stream = f->ctx->stream;
     const size_t n = static_cast<size_t>(f->width) * static_cast<size_t>(f->height);
     HIP_TRY(hipStreamSynchronize(g_stream));
     if (image) HIP_TRY(hipMemcpy(f->image, image, n * 24, hipMemcpyHostToDevice));
@@ -1019,6 +1127,8 @@ int ptk_film_upload(PtkFilm* f, const double* image, const double* position, con
 
 int ptk_film_download(PtkFilm* f, double* image, double* position, double* normal, uint64_t* counters) {
     if (!f) return fail(PTK_ERR_INVALID, "ptk_film_download: null film");
+    if (use(f->ctx) != PTK_OK) return PTK_ERR_DEVICE;
+    const hipStream_t g_stream = f->ctx->stream;
     const size_t n = static_cast<size_t>(f->width) * static_cast<size_t>(f->height);
     HIP_TRY(hipStreamSynchronize(g_stream));
     if (image) HIP_TRY(hipMemcpy(image, f->image, n * 24, hipMemcpyDeviceToHost));
@@ -1038,24 +1148,32 @@ int ptk_film_device_pointers(PtkFilm* f, double** image, double** position, doub
 }
 
 int ptk_render(PtkScene* s, PtkFilm* film, const PtkRenderJob* job) {
+    PTK_GUARD_BEGIN
     int rc = check_job(s, job, "ptk_render");
     if (rc != PTK_OK) return rc;
     if (!film || film->width != s->settings.width || film->height != s->settings.height)
         return fail(PTK_ERR_INVALID, "ptk_render: film size does not match the scene");
+    if (film->ctx != s->ctx) return fail(PTK_ERR_INVALID, "ptk_render: the film and the scene live on different devices");
+    if ((rc = use(s->ctx)) != PTK_OK) return rc;
+    const hipStream_t g_stream = s->ctx->stream;
     return for_each_batch(s, job, [&](const BatchParams& b, int64_t) {
         launch_accumulate(g_stream, b, s->results, film->image, film->position, film->normal, film->counters);
         HIP_TRY(hipGetLastError());
         s->stats.algorithmic_bytes += ACCUMULATE_BYTES_PER_PATH * b.n_paths;
         return static_cast<int>(PTK_OK);
     });
+    PTK_GUARD_END
 }
 
 int ptk_render_host(PtkScene* s, const PtkRenderJob* job, double* image, double* position, double* normal, uint64_t* counters) {
+    PTK_GUARD_BEGIN
     int rc = check_job(s, job, "ptk_render_host");
     if (rc != PTK_OK) return rc;
     if (!image || !position || !normal || !counters) return fail(PTK_ERR_INVALID, "ptk_render_host: null buffer");
+    if ((rc = use(s->ctx)) != PTK_OK) return rc;
+    const hipStream_t g_stream = s->ctx->stream;
     if (!s->host_film) {
-        rc = ptk_film_create(s->settings.width, s->settings.height, &s->host_film);
+        rc = film_create(s->ctx, s->settings.width, s->settings.height, &s->host_film);
         if (rc != PTK_OK) return rc;
     }
     PtkFilm* f = s->host_film;
@@ -1074,12 +1192,13 @@ int ptk_render_host(PtkScene* s, const PtkRenderJob* job, double* image, double*
     HIP_TRY(hipMemcpy(normal + 3 * first, f->normal + 3 * first, n * 24, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(counters + first, f->counters + first, n * 8, hipMemcpyDeviceToHost));
     return PTK_OK;
+    PTK_GUARD_END
 }
 
 const char* ptk_scene_bounce_kernel(PtkScene* s) {
     static thread_local std::string name;
     if (!s) return "";
-    name = bounce_kernel_name(s->dev);
+    name = bounce_kernel_name(s->dev, g_specialised.load());
     return name.c_str();
 }
 
@@ -1095,11 +1214,73 @@ int ptk_reset_stats(PtkScene* s) {
     return PTK_OK;
 }
 
+int ptk_selftest_record_staging(int64_t n_records, int64_t* mismatches) {
+    PTK_GUARD_BEGIN
+    if (!mismatches || n_records < 1 || n_records > (int64_t(1) << 22)) return fail(PTK_ERR_INVALID, "ptk_selftest_record_staging: 1 to 2^22 records");
+    DeviceContext* ctx = current_context();
+    if (!ctx) return PTK_ERR_DEVICE;
+    const uint32_t n = static_cast<uint32_t>(n_records);
+    const size_t padded = (static_cast<size_t>(n) + 255) & ~static_cast<size_t>(255);
+    const size_t pool_bytes = padded * RECORD_BYTES;
+    auto offset_of = [](uint32_t i, int plane) { // the layout of PathPool (scene_device.h)
+        return static_cast<size_t>(i / RECORD_TILE) * RECORD_TILE_BYTES + (i % RECORD_TILE) * 16u + static_cast<size_t>(plane) * RECORD_PLANE_STRIDE;
+    };
+    std::vector<uint32_t> words(pool_bytes / 4);
+    for (uint32_t i = 0; i < n; i++)
+        for (int plane = 0; plane < N_PLANES; plane++)
+            for (uint32_t w = 0; w < 4; w++) words[offset_of(i, plane) / 4 + w] = (i * 2654435761u) ^ (static_cast<uint32_t>(plane) * 0x9E3779B9u + w * 0x85EBCA6Bu);
+    std::vector<uint32_t> list(n);
+    uint32_t state = 12345u;
+    for (uint32_t i = 0; i < n; i++) { // arbitrary sources, as a class-sorted list has them
+        state = state * 1664525u + 1013904223u;
+        list[i] = (state >> 8) % n;
+    }
+    const uint32_t noise_mask = (1u << 16) - 1;
+    std::vector<double> noise(noise_mask + 1, 1.0);
+    DeviceBuffers tmp;
+    PathPool in{}, out{};
+    uint32_t* d_list = nullptr;
+    double *d_noise = nullptr, *d_sink = nullptr;
+    const uint32_t blocks = std::min<uint32_t>((n + 255) / 256, 4 * ctx->compute_units);
+    HIP_TRY(tmp.alloc(&in.base, pool_bytes));
+    HIP_TRY(tmp.alloc(&out.base, pool_bytes));
+    HIP_TRY(tmp.alloc(&d_list, n));
+    HIP_TRY(tmp.alloc(&d_noise, noise.size()));
+    HIP_TRY(tmp.alloc(&d_sink, static_cast<size_t>(blocks) * 256));
+    HIP_TRY(hipMemcpy(in.base, words.data(), pool_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(out.base, 0, pool_bytes));
+    HIP_TRY(hipMemcpy(d_list, list.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_noise, noise.data(), noise.size() * sizeof(double), hipMemcpyHostToDevice));
+    launch_selftest_staging(ctx->stream, blocks, in, out, d_list, n, d_noise, noise_mask, d_sink);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> got(pool_bytes / 4);
+    HIP_TRY(hipMemcpy(got.data(), out.base, pool_bytes, hipMemcpyDeviceToHost));
+    int64_t bad = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        bool same = true;
+        for (int plane = 0; plane < N_PLANES; plane++)
+            for (uint32_t w = 0; w < 4; w++) {
+                const uint32_t want = i % 5u == 3u ? 0u : words[offset_of(list[i], plane) / 4 + w]; // skipped lanes write nothing
+                same = same && got[offset_of(i, plane) / 4 + w] == want;
+            }
+        if (!same) bad++;
+    }
+    *mismatches = bad;
+    return PTK_OK;
+    PTK_GUARD_END
+}
+
 // ---- denoise --------------------------------------------------------------------------------------
-int ptk_denoise_device(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t width, int32_t height, double* d_image,
-                       const double* d_position, const double* d_normal, double* d_scratch) {
-    if (require_init() != PTK_OK) return PTK_ERR_DEVICE;
-    if ((!tasks && n_tasks > 0) || width < 1 || height < 1 || !d_image || !d_position || !d_normal || !d_scratch)
+} // extern "C"
+
+namespace {
+// The pipeline on device buffers (both device entry points): every kernel reads one image buffer and writes the other,
+// every pixel of it, so the scratch buffer needs no particular contents on entry.  Allocates nothing.
+int denoise_on_device(DeviceContext* ctx, const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t width, int32_t height, double* d_image,
+                      const double* d_position, const double* d_normal, double* d_scratch) {
+    const hipStream_t g_stream = ctx->stream;
+    if ((!tasks && n_tasks > 0) || n_tasks < 0 || width < 1 || height < 1 || !d_image || !d_position || !d_normal || !d_scratch)
         return fail(PTK_ERR_INVALID, "ptk_denoise_device: bad argument");
     const size_t bytes = static_cast<size_t>(width) * static_cast<size_t>(height) * 24;
     // The whole pipeline is checked before its first kernel runs.  An a-trous tap lies up to 2^iterations pixels from
@@ -1153,11 +1334,24 @@ int ptk_denoise_device(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t wid
     if (src != d_image) HIP_TRY(hipMemcpyAsync(d_image, src, bytes, hipMemcpyDeviceToDevice, g_stream));
     return PTK_OK;
 }
+} // namespace
+
+extern "C" {
+
+int ptk_denoise_device(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t width, int32_t height, double* d_image,
+                       const double* d_position, const double* d_normal, double* d_scratch) {
+    DeviceContext* ctx = current_context();
+    if (!ctx) return PTK_ERR_DEVICE;
+    return denoise_on_device(ctx, tasks, n_tasks, width, height, d_image, d_position, d_normal, d_scratch);
+}
 
 int ptk_denoise(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t width, int32_t height, double* image,
                 const double* position, const double* normal) {
-    if (require_init() != PTK_OK) return PTK_ERR_DEVICE;
-    if ((!tasks && n_tasks > 0) || width < 1 || height < 1 || !image || !position || !normal)
+    PTK_GUARD_BEGIN
+    DeviceContext* ctx = current_context();
+    if (!ctx) return PTK_ERR_DEVICE;
+    const hipStream_t g_stream = ctx->stream;
+    if ((!tasks && n_tasks > 0) || n_tasks < 0 || width < 1 || height < 1 || !image || !position || !normal)
         return fail(PTK_ERR_INVALID, "ptk_denoise: bad argument");
     const size_t n = static_cast<size_t>(width) * static_cast<size_t>(height) * 3;
     DeviceBuffers tmp;
@@ -1174,6 +1368,7 @@ int ptk_denoise(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t width, int
     HIP_TRY(hipStreamSynchronize(g_stream));
     HIP_TRY(hipMemcpy(image, d_image, n * 8, hipMemcpyDeviceToHost));
     return PTK_OK;
+    PTK_GUARD_END
 }
 
 } // extern "C"

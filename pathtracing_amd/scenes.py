@@ -259,6 +259,52 @@ def mesh_box(directory, n_lon=64, n_lat=33, material="gold", smooth=True, textur
     return n_tri
 
 
+def write_thicket_obj(path, n_triangles=6000, seed=5):
+    """A mesh no tessellator would produce: triangles of geometrically growing size nested around one point
+    (a surface-area hierarchy peels them off one at a time and grows deep), tight clusters of tiny triangles,
+    and long thin triangles that span the whole mesh.  Plain `v` / `f a b c` lines."""
+    rng = np.random.default_rng(seed)
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    centres = rng.uniform(-0.8, 0.8, size=(7, 3))
+    with open(path, "w") as f:
+        f.write("# generated thicket\n")
+        faces = []
+        for i in range(n_triangles):
+            kind = i % 4
+            if kind < 2:    # nested around the origin
+                c = np.zeros(3)
+                extent = 1e-8 * 1.35 ** (i // 4 % 60)
+                d = rng.normal(size=(3, 3)) * extent
+            elif kind == 2:  # a cluster of tiny triangles
+                c = centres[i // 4 % 7] + rng.normal(size=3) * 1e-3
+                d = rng.normal(size=(3, 3)) * 2e-4
+            else:            # long and thin
+                c = rng.uniform(-0.5, 0.5, size=3)
+                axis = i // 4 % 3
+                d = rng.normal(size=(3, 3)) * 2e-4
+                d[:, axis] = np.array([-1.0, 1.0, 0.9]) * rng.uniform(0.5, 1.0)
+            for k in range(3):
+                f.write("v %.12g %.12g %.12g\n" % tuple(c + d[k]))
+            faces.append("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
+        f.write("".join(faces))
+    return n_triangles
+
+
+def thicket_box(directory, material="gold", n_triangles=6000, **settings):
+    """Cornell walls + ceiling light + the mesh of write_thicket_obj (flat shading, no texture coordinates)."""
+    os.makedirs(directory, exist_ok=True)
+    write_thicket_obj(os.path.join(directory, "models", "thicket.obj"), n_triangles)
+    name = {"gold": "gold_material", "rough_glass": "rough_glass_material"}[material]
+    mesh = {"name": "mesh", "type": "Object", "subtype": "ObjectUnion",
+            "parameters": {"file": "models/thicket.obj", "material": name, "enable_smooth_shading": False,
+                           "center": [0.0, 0.9, -0.8], "size": 0.8, "orientation": {"X": 10, "Y": 25, "Z": 5}}}
+    scene = {"valuemaps": list(_BASE_MAPS), "media": list(_BASE_MEDIA), "materials": list(_BASE_MATERIALS),
+             "objects": _cornell_shell() + [mesh, _LIGHT], "background_medium": "air_medium",
+             "background_color": [0.0, 0.0, 0.0], "camera": dict(_EXAMPLE_CAMERA)}
+    write_scene_directory(directory, scene, default_settings(**settings))
+    return directory
+
+
 def material_zoo(directory, dof=None, **settings):
     """One small box exercising every material, object, light and texture path:
     Plane floor, top-level Triangle, Glossy / Reflective / Transparent / all microfacet types,

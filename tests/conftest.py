@@ -37,5 +37,6 @@ def scene_dirs(scene_root):
     dirs["cloud"] = scenes.cloud_box(os.path.join(root, "cloud"), WIDTH=64, HEIGHT=48)
     dirs["fog"] = scenes.cloud_box(os.path.join(root, "fog"), fog=True, WIDTH=64, HEIGHT=48)
     dirs["lamp"] = scenes.emissive_mesh_box(os.path.join(root, "lamp"), WIDTH=64, HEIGHT=48)
+    dirs["thicket"] = scenes.thicket_box(os.path.join(root, "thicket"), WIDTH=64, HEIGHT=48)
     dirs["room"] = scenes.living_room(os.path.join(root, "room"), mesh_lon=32, mesh_lat=17, texture_size=64, WIDTH=64, HEIGHT=48)
     return dirs

@@ -42,6 +42,7 @@ SCENES = {
     "cloud": ("cloud_box", dict(WIDTH=48, HEIGHT=32), 3),
     "fog": ("cloud_box", dict(fog=True, WIDTH=48, HEIGHT=32), 3),
     "lamp": ("emissive_mesh_box", dict(WIDTH=48, HEIGHT=32), 3),
+    "thicket": ("thicket_box", dict(WIDTH=48, HEIGHT=32), 3),
     "room": ("living_room", dict(mesh_lon=24, mesh_lat=13, texture_size=64, WIDTH=48, HEIGHT=32), 3),
 }
 SEEDS = (101, 202, 303)

@@ -8,6 +8,7 @@ import sys
 
 import pytest
 
+import pathtracing_amd as pt
 from pathtracing_amd import _ffi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -74,3 +75,15 @@ def test_product_code_never_touches_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".sh")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+
+
+def test_buffer_arguments_are_checked_before_they_reach_the_library():
+    """The C ABI takes plain pointers; the Python layer refuses arrays whose layout is not what they point at."""
+    import numpy as np
+    with pytest.raises(TypeError):
+        pt._dp(np.zeros(4, dtype=np.float32))
+    with pytest.raises(TypeError):
+        pt._dp(np.zeros((4, 4))[:, ::2])
+    with pytest.raises(TypeError):
+        pt._u64p(np.zeros(4, dtype=np.int32))
+    assert pt._dp(None) is None and pt._dp(np.zeros(3)) is not None

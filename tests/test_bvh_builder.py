@@ -26,3 +26,18 @@ def checker(tmp_path_factory):
 def test_builder_output_is_a_valid_hierarchy(checker, n, max_leaf, seed):
     out = subprocess.run([checker, str(n), str(max_leaf), str(seed)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+
+
+# Meshes that are nothing like a tessellated surface.  The walk on the GPU has 64 stack entries; the builder reports
+# what its tree needs (the checker recomputes it from the tree's shape) and builds again with a shallower tree when the
+# surface-area heuristic's would need more: "sliver" needs about 100 entries without that.
+@pytest.mark.parametrize("n,max_leaf,seed,shape,limit", [(6000, 2, 3, "sliver", 64), (50000, 1, 3, "sliver", 64),
+                                                         (50000, 1, 3, "sliver", 30), (60000, 2, 5, "clustered", 64),
+                                                         (60000, 2, 5, "clustered", 20)])
+def test_stack_need_is_bounded_on_lopsided_meshes(checker, n, max_leaf, seed, shape, limit):
+    out = subprocess.run([checker, str(n), str(max_leaf), str(seed), shape, str(limit)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+    stack = int(out.stdout.split("stack=")[1].split()[0])
+    assert stack <= 64
+    if shape == "sliver" and limit == 64:
+        assert "sah_levels=56" not in out.stdout  # the fallback was exercised

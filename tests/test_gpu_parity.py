@@ -11,7 +11,7 @@ import pathtracing_amd as pt
 pytestmark = pytest.mark.gpu
 
 SCENES = ["example", "zoo", "zoo_circle", "zoo_square", "mesh_gold", "mesh_rough_glass", "mesh_glass",
-          "mesh_textured", "cloud", "fog", "lamp", "room"]
+          "mesh_textured", "cloud", "fog", "lamp", "thicket", "room"]
 
 
 @pytest.fixture(scope="module")
@@ -349,3 +349,14 @@ def test_degenerate_jobs_and_scenes(tmp_path, ob):
     # out-of-range jobs are refused, not clamped
     with pytest.raises(pt.PtkError):
         dev.render(film, pt.make_job(32 * 24 - 1, 2, 1, 0, 1))
+
+
+def test_record_staging_through_lds_delivers_every_record():
+    """k_bounce prefetches its records with asynchronous loads straight into LDS and reads them back behind
+    hand-written wait counts (request_record / staged_record in path_kernels.h).  The library's self-test pushes
+    records through that very pair, with other loads in flight and lanes switched off; none may differ."""
+    import ctypes as C
+    bad = C.c_int64(-1)
+    for n in (1, 255, 4096, 1 << 20):
+        assert pt.device_lib().ptk_selftest_record_staging(n, C.byref(bad)) == 0, pt.device_lib().ptk_last_error()
+        assert bad.value == 0, (n, bad.value)
