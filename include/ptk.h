@@ -321,6 +321,16 @@ int ptk_denoise(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t width, int
  * the same size).  Asynchronous on the library's stream. */
 int ptk_denoise_device(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t width, int32_t height,
                        double* d_image, const double* d_position, const double* d_normal, double* d_scratch);
+/* ptk_denoise_device without the scratch argument and without any allocation.  No counterpart in the
+ * reference: it is for callers that cannot allocate device memory -- code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  The ping-pong buffer is a static array in device memory
+ * that every GPU the library runs on holds from load time to process exit: 48 MiB, enough for images of at
+ * most 2,097,152 pixels (1920x1080 fits); larger images are refused with PTK_ERR_MEMORY.  The call makes no
+ * hipMalloc/hipFree and no allocating library call; same kernels, same results as ptk_denoise_device.
+ * All calls on one GPU share that GPU's array: two that overlap in time (different host threads, or streams
+ * other than the library's) race.  Asynchronous on the library's stream. */
+int ptk_denoise_device_static(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t width, int32_t height,
+                              double* d_image, const double* d_position, const double* d_normal);
 
 #ifdef __cplusplus
 }

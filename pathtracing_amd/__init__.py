@@ -329,6 +329,14 @@ def denoise_film(tasks, film, scratch_film):
     _check_dev(device_lib().ptk_denoise_device(arr, len(tasks), film.width, film.height, img, pos, nrm, scratch))
 
 
+def denoise_film_static(tasks, film):
+    """denoise_film without a scratch film and without any device allocation: the library's static scratch
+    buffer is used (images of at most 2,097,152 pixels; see ptk_denoise_device_static in include/ptk.h)."""
+    img, pos, nrm, _ = film.device_pointers()
+    arr = (PtkDenoiseTask * len(tasks))(*tasks)
+    _check_dev(device_lib().ptk_denoise_device_static(arr, len(tasks), film.width, film.height, img, pos, nrm))
+
+
 def denoise(tasks, image, position, normal):
     """Applies a denoising pipeline on the GPU; returns the filtered copy of `image`."""
     init(_dev_initialised if _dev_initialised is not None else 0)

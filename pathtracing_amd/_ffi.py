@@ -134,6 +134,8 @@ DEVICE_PROTOTYPES = {
     "ptk_denoise": (C.c_int, [C.POINTER(PtkDenoiseTask), C.c_int32, C.c_int32, C.c_int32, dptr, dptr, dptr]),
     "ptk_denoise_device": (C.c_int, [C.POINTER(PtkDenoiseTask), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ptk_denoise_device_static": (C.c_int, [C.POINTER(PtkDenoiseTask), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]),
 }
 
 

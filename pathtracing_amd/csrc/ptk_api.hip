@@ -27,6 +27,15 @@ namespace {
 
 thread_local std::string g_error;
 
+// Scratch space of ptk_denoise_device_static, the entry point that allocates nothing: room for one float64 [H][W][3]
+// image of up to STATIC_SCRATCH_PIXELS pixels (48 MiB).  Every device the library runs on holds its own copy of the
+// array at its own address, from the moment the code object is loaded until the process ends.  In host code the
+// array's name is only a handle for hipGetSymbolAddress: the address kernels and copies use is looked up once per
+// device in ptk_init (DeviceContext::static_scratch) and nothing else may touch `scratch` by name.
+constexpr int64_t STATIC_SCRATCH_PIXELS = int64_t(1) << 21;
+constexpr size_t STATIC_SCRATCH_BYTES = static_cast<size_t>(STATIC_SCRATCH_PIXELS) * 24;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
 // One context per device the process has initialised (ptk_init): the library's stream on that device and what the
 // launchers need to know about it.  Scenes and films remember the context they were created in, so one process can
 // drive several GPUs, one host thread per GPU; calls without a scene or film argument use the device the calling thread
@@ -35,6 +44,7 @@ struct DeviceContext {
     int device = -1;
     hipStream_t stream = nullptr;
     uint32_t compute_units = 256;
+    double* static_scratch = nullptr; // this device's copy of `scratch` (hipGetSymbolAddress, with the device current)
 };
 constexpr int MAX_DEVICES = 64;
 DeviceContext g_contexts[MAX_DEVICES];
@@ -523,6 +533,10 @@ int ptk_init(int device) {
             return fail(PTK_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", but the kernels are built for gfx950 only");
         if (prop.multiProcessorCount > 0) ctx.compute_units = static_cast<uint32_t>(prop.multiProcessorCount);
         HIP_TRY(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+        void* address = nullptr; // of this device's copy of the static scratch array (the device is current)
+        HIP_TRY(hipGetSymbolAddress(&address, HIP_SYMBOL(scratch)));
+        if (!address) return fail(PTK_ERR_DEVICE, "ptk_init: the static scratch array has no address on this device");
+        ctx.static_scratch = static_cast<double*>(address);
         ctx.device = device;
     }
     t_device = device;
@@ -1343,6 +1357,17 @@ int ptk_denoise_device(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t wid
     DeviceContext* ctx = current_context();
     if (!ctx) return PTK_ERR_DEVICE;
     return denoise_on_device(ctx, tasks, n_tasks, width, height, d_image, d_position, d_normal, d_scratch);
+}
+
+int ptk_denoise_device_static(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t width, int32_t height, double* d_image,
+                              const double* d_position, const double* d_normal) {
+    DeviceContext* ctx = current_context();
+    if (!ctx) return PTK_ERR_DEVICE;
+    if (width < 1 || height < 1) return fail(PTK_ERR_INVALID, "ptk_denoise_device_static: empty image");
+    if (static_cast<int64_t>(width) * height > STATIC_SCRATCH_PIXELS)
+        return fail(PTK_ERR_MEMORY, "ptk_denoise_device_static: the image has more than 2097152 pixels, the size of the library's static "
+                                    "scratch buffer; use ptk_denoise_device with a scratch buffer of your own");
+    return denoise_on_device(ctx, tasks, n_tasks, width, height, d_image, d_position, d_normal, ctx->static_scratch);
 }
 
 int ptk_denoise(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t width, int32_t height, double* image,
