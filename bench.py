@@ -6,17 +6,29 @@
 Metric: Mpaths/s (whole job).  A path is one camera sample (one `raytrace` call of the reference,
 app/pathtracer.cpp:39).  A step renders `--spp-per-step` samples of every pixel of the frame and
 folds them into the device-resident film; scene, path pools and film are in HBM before the timed
-region starts.  At N > 1 (launched by torch.distributed.run, one rank per GPU) every rank renders
-its own slice of sample indices of the whole frame -- per-GPU work fixed, weak scaling -- and the
-films are summed over RCCL once at the end of the timed region.
+region starts.  At N > 1 (launched by torch.distributed.run, one rank per GPU) the work of a step is
+partitioned with per-GPU work fixed (weak scaling) in one of two ways (`--partition`):
 
-Workloads (`--workload`):
-  example   the reference's scenes/example Cornell box at 1920x1080 (benchmark configuration 2)
-  mesh      Cornell walls + a generated 1,048,576-triangle OBJ mesh at 1920x1080
-  cloud     scattering-medium + coloured-glass scene at 1920x1080
-  room      living-room stand-in (23 objects, textured OBJ meshes, file textures, sphere light) at 1920x1080
+  samples  every rank renders its own slice of sample indices of the whole frame; the films are combined
+           with one weighted-mean all-reduce (RCCL) at the end of the timed region
+  tiles    the frame is N times as tall; every rank owns the interleaved bands of rows `distributed.row_bands`
+           gives it and renders only those pixels; the films are combined by the same collective, which for
+           disjoint pixels is a gather
+
+`value` is the headline workload (`--workload`, default the reference's scenes/example at 1920x1080).  The default
+run also measures, in the same process, the other half of the metric -- a generated 1,048,576-triangle mesh in the
+Cornell box at 1080p, reported under "mesh" -- and the reference's shipped denoising pipeline on a frame of the
+scattering-medium scene, reported under "denoise" (`--only-headline` skips both).
+
+Workloads:
+  example   the reference's scenes/example Cornell box (benchmark configuration 2)
+  mesh      Cornell walls + a generated 1,048,576-triangle OBJ mesh (MetallicMicrofacet)
+  cloud     scattering-medium + coloured-glass scene
+  room      living-room stand-in (23 objects, textured OBJ meshes, file textures, sphere light)
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -28,7 +40,11 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak
+F64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (AMD's specification; half the 157.3 TFLOP/s fp32 vector rate)
+CLASS_NAMES = ["Diffuse", "Reflective", "Transparent", "Glossy", "MetallicMicrofacet", "ReflectiveMicrofacet",
+               "TransparentMicrofacet", "MediumScatter"]
+PROFILE_EVERY = 4  # HIP events bracket the kernel families on every fourth timed step (event records drain the queue)
 
 
 def parse_args():
@@ -37,33 +53,51 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="example", choices=["example", "mesh", "cloud", "room"])
+    ap.add_argument("--partition", default="samples", choices=["samples", "tiles"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp-per-step", type=int, default=8)
     ap.add_argument("--mesh-lon", type=int, default=1024)
     ap.add_argument("--mesh-lat", type=int, default=513)
+    ap.add_argument("--mesh-steps", type=int, default=8, help="timed steps of the mesh sub-record")
+    ap.add_argument("--only-headline", action="store_true", help="skip the mesh and denoise sub-records")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--denoise", action="store_true", help="also time the shipped denoising pipeline on the device film")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="library tuning knob (ptk_set_option)")
     ap.add_argument("--tail-records", type=int, default=-1, help="override the library's tail_records knob")
     ap.add_argument("--bvh-leaf-size", type=int, default=0, help="override the scene setting bvh_leaf_size (mesh workload)")
     return ap.parse_args()
 
 
-def build_workload(args, directory):
+def sources_hash():
+    """Hash of the device library's sources: profiles kept under profiles/ record it, so a counter file measured on
+    other code than the one running is recognised (there is no git on the GPU box)."""
+    h = hashlib.sha256()
+    files = []
+    for pattern in ("*.hip", "*.h", "*/*.hip", "*/*.h", "*/*.cpp", "*/*/*.hip", "*/*/*.h"):
+        files += glob.glob(os.path.join(ROOT, "pathtracing_amd", "csrc", pattern))
+    for path in sorted(set(files)):
+        if os.sep + "build" + os.sep in path:
+            continue
+        h.update(os.path.relpath(path, ROOT).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def build_workload(args, workload, directory, width, height, spp, steps):
     from pathtracing_amd import scenes
-    settings = dict(WIDTH=args.width, HEIGHT=args.height, samples_per_pixel=args.spp_per_step * args.steps,
-                    samples_per_iteration=args.spp_per_step)
+    settings = dict(WIDTH=width, HEIGHT=height, samples_per_pixel=spp * steps, samples_per_iteration=spp)
     if args.bvh_leaf_size > 0:
         settings["bvh_leaf_size"] = args.bvh_leaf_size
-    if args.workload == "example":
+    if workload == "example":
         scenes.cornell_example(directory, **settings)
         return "scenes/example Cornell box (12 analytic objects)"
-    if args.workload == "mesh":
+    if workload == "mesh":
         n = scenes.mesh_box(directory, n_lon=args.mesh_lon, n_lat=args.mesh_lat, material="gold", smooth=True, **settings)
         return f"Cornell walls + generated {n}-triangle OBJ mesh (MetallicMicrofacet)"
-    if args.workload == "room":
+    if workload == "room":
         scenes.living_room(directory, mesh_lon=256, mesh_lat=129, texture_size=1024, **settings)
         return "living-room stand-in: 23 objects, 5 OBJ meshes (294,912 triangles), 1024^2 file textures, sphere light"
     scenes.cloud_box(directory, **settings)
@@ -75,31 +109,31 @@ def scenes_default_pipeline():
     return [dict(mode=t["mode"], **t["parameters"]) for t in scenes.DEFAULT_DENOISING["pipeline"]]
 
 
-def cpu_baseline(host_scene, args, threads):
+def cpu_baseline(host_scene, width, height, seed, threads):
     """The CPU restatement (oracle/) on this box's host cores, on a bounded sample of the same frame."""
     from oracle import binding as ob
     import pathtracing_amd as pt
-    W, H = args.width, args.height
+    W, H = width, height
     osc = ob.OracleScene(host_scene)
     image, pos, nrm = np.zeros((H, W, 3)), np.zeros((H, W, 3)), np.zeros((H, W, 3))
     cnt = np.zeros((H, W), dtype=np.uint64)
     # calibrate on a thin slice, then size the sample for roughly 12 s
     rows = max(1, H // 135)
-    job = pt.make_job(0, rows * W, 1, 0, args.seed)
+    job = pt.make_job(0, rows * W, 1, 0, seed)
     t0 = time.perf_counter()
     osc.render(job, image, pos, nrm, cnt, threads=threads)
     rate = rows * W / max(time.perf_counter() - t0, 1e-9)
     # the thin slice underestimates the rate (thread start-up, one region of the frame): a whole frame at a sample
     # count sized for about a second gives the figure the final sample is sized with
     spp = int(max(1, min(64, rate * 1.0 / (W * H))))
-    job = pt.make_job(0, W * H, spp, 0, args.seed)
+    job = pt.make_job(0, W * H, spp, 0, seed)
     t0 = time.perf_counter()
     osc.render(job, image, pos, nrm, cnt, threads=threads)
     rate = max(rate, W * H * spp / max(time.perf_counter() - t0, 1e-9))
     budget = rate * 12.0  # paths
     spp = int(max(1, min(256, budget / (W * H))))
     n_pixels = W * H if budget >= W * H else int(max(W, budget // W * W))
-    job = pt.make_job(0, n_pixels, spp, 1, args.seed)
+    job = pt.make_job(0, n_pixels, spp, 1, seed)
     t0 = time.perf_counter()
     osc.render(job, image, pos, nrm, cnt, threads=threads)
     dt = time.perf_counter() - t0
@@ -109,38 +143,81 @@ def cpu_baseline(host_scene, args, threads):
                       "fp64 CPU restatement of the reference with the same counter-based random streams"}
 
 
-def main():
-    args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    # PTK_BENCH_FORCE_DISTRIBUTED=1 takes the multi-GPU path (torch tensors, RCCL all-reduce) with any world
-    # size, so that it can be rehearsed on a one-GPU box
-    distributed = world > 1 or os.environ.get("PTK_BENCH_FORCE_DISTRIBUTED") == "1"
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    import pathtracing_amd as pt
+def profile_entry(name, workload, kernel, code):
+    """Per-kernel figures of the last rocprofv3 counter passes kept under profiles/ (tools/profile_round.sh,
+    tools/pmc_pass.sh and their digests), with whether they were measured on the code that is running."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, None
+    try:
+        with open(path) as f:
+            data = json.load(f)
+        entry = data.get(workload, {}).get(kernel)
+        measured_on = data.get("_sources", {}).get(workload)
+        return entry, {"file": "profiles/" + name, "measured_on_sources": measured_on, "current_sources": code,
+                       "stale": measured_on != code}
+    except Exception:
+        return None, None
 
-    pt.init(local_rank)
-    if args.tail_records >= 0:
-        pt.set_option("tail_records", args.tail_records)
-    tmp = tempfile.mkdtemp(prefix=f"ptk_bench_r{rank}_")
-    workload_name = build_workload(args, tmp)
+
+class Distributed:
+    """torch.distributed (RCCL) state of this rank; inert in a single-process run."""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        # PTK_BENCH_FORCE_DISTRIBUTED=1 takes the multi-GPU path (torch tensors, RCCL collectives) with any world
+        # size, so that it can be rehearsed on a one-GPU box
+        self.on = self.world > 1 or os.environ.get("PTK_BENCH_FORCE_DISTRIBUTED") == "1"
+        if self.on:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29512")
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            torch.cuda.set_device(self.local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank), rank=self.rank,
+                                    world_size=self.world)
+
+    def barrier(self, pt):
+        pt.sync()
+        if self.on:
+            self.torch.cuda.synchronize()
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if not self.on:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.torch.device("cuda", self.local_rank))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.on:
+            self.dist.destroy_process_group()
+
+
+def run_workload(pt, args, ds, workload, width, height, spp, steps, warmup, code):
+    """W untimed steps, then exactly K timed ones between barriers; returns the record of the workload."""
+    from pathtracing_amd.distributed import band_job, combine_films, sample_slice
+    rank, world = ds.rank, ds.world
+    tiles = args.partition == "tiles"
+    frame_height = height * world if tiles else height  # tiles: per-GPU pixel count fixed, the frame grows
+    tmp = tempfile.mkdtemp(prefix=f"ptk_bench_{workload}_r{rank}_")
+    workload_name = build_workload(args, workload, tmp, width, frame_height, spp, steps)
     t_build = time.perf_counter()
     host_scene = pt.load_scene_directory(tmp)
-    W, H = args.width, args.height
+    W, H = width, frame_height
     n_pixels = W * H
-    spp = args.spp_per_step
-    scene = pt.DeviceScene(host_scene, max_paths_in_flight=max(n_pixels * spp, 1 << 22))
+    band_start, own_pixels, band_pixels, band_stride = band_job(rank, world, W, H, band_rows=8) if tiles else (0, n_pixels, 0, 0)
+    scene = pt.DeviceScene(host_scene, max_paths_in_flight=max(width * height * spp, 1 << 22))
     build_s = time.perf_counter() - t_build
 
-    if distributed:
-        import torch
-        dev = torch.device("cuda", local_rank)
+    if ds.on:
+        torch = ds.torch
+        dev = torch.device("cuda", ds.local_rank)
         t_img = torch.zeros(n_pixels * 3, dtype=torch.float64, device=dev)
         t_pos = torch.zeros(n_pixels * 3, dtype=torch.float64, device=dev)
         t_nrm = torch.zeros(n_pixels * 3, dtype=torch.float64, device=dev)
@@ -150,34 +227,25 @@ def main():
     else:
         film = pt.Film(W, H)
 
-    def barrier():
-        pt.sync()
-        if distributed:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+    # samples: every rank owns a disjoint slice of sample indices (weak scaling: the slice length is fixed)
+    total_spp = spp * (warmup + steps)
+    offset = 0 if tiles else sample_slice(rank, world, total_spp * world)[0]
 
-    # every rank owns a disjoint slice of sample indices (weak scaling: the slice length is fixed)
-    from pathtracing_amd.distributed import combine_films, sample_slice
-    total_spp = spp * (args.warmup + args.steps)
-    offset, _ = sample_slice(rank, world, total_spp * world)
-
-    # Kernels are timed with HIP events on the library's stream on every PROFILE_EVERY-th step of the
-    # timed region (event records drain the queue, so timing every step would slow the run).
-    PROFILE_EVERY = 4
-    CLASS_NAMES = ["Diffuse", "Reflective", "Transparent", "Glossy", "MetallicMicrofacet", "ReflectiveMicrofacet",
-                   "TransparentMicrofacet", "MediumScatter"]
     profiled = {"steps": 0}
     fam = {"k_bounce": [0.0, 0, 0], "k_bin": [0.0, 0, 0], "k_traverse": [0.0, 0, 0]}  # ms, bytes, launches
     other_ms = [0.0]
 
+    def render_step(i):
+        if tiles:  # the interleaved 8-row bands of this rank as one banded job
+            scene.render_bands(film, pt.make_job(band_start, own_pixels, spp, i * spp, args.seed), band_pixels, band_stride)
+        else:
+            scene.render(film, pt.make_job(0, n_pixels, spp, offset + i * spp, args.seed))
+
     def step(i, timed=False):
-        job = pt.make_job(0, n_pixels, spp, offset + i * spp, args.seed)
-        if timed and (i - args.warmup) % PROFILE_EVERY == 0:
+        if timed and (i - warmup) % PROFILE_EVERY == 0:
             s0 = scene.stats()
             pt.set_profiling(True)
-            scene.render(film, job)
+            render_step(i)
             pt.set_profiling(False)
             s1 = scene.stats()
             profiled["steps"] += 1
@@ -187,93 +255,94 @@ def main():
                 fam[k][2] += getattr(s1, f + "_launches") - getattr(s0, f + "_launches")
             other_ms[0] += s1.other_ms - s0.other_ms
         else:
-            scene.render(film, job)
+            render_step(i)
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
-    if distributed and args.warmup > 0:
+    if ds.on and warmup > 0:
         # the warm-up also runs the combine once: RCCL sets up its channels and torch's allocator gets its
         # blocks at the first large collective, which would otherwise fall inside the timed region
         pt.sync()
         combine_films(t_img, t_pos, t_nrm, t_cnt)
-        torch.cuda.synchronize()
-    barrier()
+        ds.torch.cuda.synchronize()
+    ds.barrier(pt)
     film.clear()
     scene.reset_stats()
-    barrier()
+    ds.barrier(pt)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, timed=True)
+    for i in range(steps):
+        step(warmup + i, timed=True)
     pt.sync()
-    if distributed:
-        import torch
-        # combine the per-GPU sample slices: weighted mean over RCCL, once per flush
+    if ds.on:
+        # combine the per-GPU films: weighted mean over RCCL, once per flush (disjoint pixels: a gather)
         combine_films(t_img, t_pos, t_nrm, t_cnt)
-        torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        import torch
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        ds.torch.cuda.synchronize()
+    ds.barrier(pt)
+    elapsed = ds.max_over_ranks(time.perf_counter() - t0)
 
     st = scene.stats()
-    paths_per_rank = n_pixels * spp * args.steps
-    total_paths = paths_per_rank * world
+    total_paths = own_pixels * spp * steps * world
     value = total_paths / elapsed / 1e6
 
     # The dominant kernel, timed with HIP events on the library's stream over the profiled steps of this timed
     # region and named as rocprofv3 shows it: k_bounce (every path vertex: shading, shadow ray, extension ray; in
     # scenes with meshes its time includes the resume pass) or, in scenes with meshes, k_traverse.
-    if fam["k_traverse"][0] > fam["k_bounce"][0]:
-        kernel = "ptk::k_traverse"
-        d_ms, d_bytes, d_launches = fam["k_traverse"]
-    else:
-        kernel = scene.bounce_kernel()
-        d_ms, d_bytes, d_launches = fam["k_bounce"]
-    achieved = d_bytes / (d_ms * 1e-3) / 1e9 if d_ms > 0 else 0.0
-    traffic = None
-    traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(traffic_file):
-        try:
-            with open(traffic_file) as f:
-                traffic = json.load(f).get(args.workload, {}).get(kernel)
-        except Exception:
-            traffic = None
-    # SQ counters of the same kernel from the last rocprofv3 --pmc passes kept under profiles/ (tools/counters_digest.py):
-    # the share of the SIMDs' issue slots spent on vector instructions and the occupancy the kernel is compiled for
+    traverse = fam["k_traverse"][0] > fam["k_bounce"][0]
+    kernel = "ptk::k_traverse" if traverse else scene.bounce_kernel()
+    d_ms, d_bytes, d_launches = fam["k_traverse"] if traverse else fam["k_bounce"]
+    ms_per_launch = d_ms / max(d_launches, 1)
+    algorithmic_gbs = d_bytes / (d_ms * 1e-3) / 1e9 if d_ms > 0 else 0.0
+    traffic, traffic_source = profile_entry("traffic_latest.json", workload, kernel, code)
+    counters, counters_source = profile_entry("counters_latest.json", workload, kernel, code)
+    hbm = {"algorithmic_GBps": algorithmic_gbs, "algorithmic_frac_of_peak": algorithmic_gbs / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_launch": d_bytes / max(d_launches, 1), "peak_GBps": HBM_PEAK_GBS}
+    if traffic and ms_per_launch > 0:
+        # measured HBM bytes per launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, separate passes) over the live launch time
+        hbm["measured_bytes_per_launch"] = traffic
+        hbm["measured_GBps"] = traffic / (ms_per_launch * 1e-3) / 1e9
+        hbm["measured_frac_of_peak"] = hbm["measured_GBps"] / HBM_PEAK_GBS
+        hbm["measured_over_algorithmic"] = traffic / max(d_bytes / max(d_launches, 1), 1)
+        hbm["source"] = traffic_source
     valu = None
-    counters_file = os.path.join(ROOT, "profiles", "counters_latest.json")
-    if os.path.exists(counters_file):
-        try:
-            with open(counters_file) as f:
-                c = json.load(f).get(args.workload, {}).get(kernel)
-            if c and "valu_share_of_wave_time" in c:
-                waves_per_simd = 5 if kernel == "ptk::k_traverse" else 2
-                valu = {"waves_per_simd": waves_per_simd, "occupancy_frac_of_8": waves_per_simd / 8.0,
-                        "simd_issue_busy": c["valu_share_of_wave_time"] * waves_per_simd,
-                        "active_lanes_per_instruction": c.get("active_lanes_per_valu"),
-                        "valu_instructions_per_wave": c.get("valu_per_wave"), "source": "profiles/counters_latest.json"}
-        except Exception:
-            valu = None
-    vertices_by_class = {CLASS_NAMES[c]: int(st.class_vertices[c]) for c in range(8) if st.class_vertices[c]}
-    roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu": valu,
-                "bytes_per_launch": d_bytes / max(d_launches, 1), "ms_per_launch": d_ms / max(d_launches, 1),
-                "launches": int(d_launches), "profiled_steps": profiled["steps"],
-                "device_ms": {"k_bounce": fam["k_bounce"][0], "k_bin": fam["k_bin"][0], "k_traverse": fam["k_traverse"][0],
-                              "other": other_ms[0]},
-                "vertices_by_class": vertices_by_class}
-
-    out = {
-        "metric": "Mpaths/s (whole node) at 1080p, scenes/example + 1M-tri mesh, 1/2/4/8 GPUs",
-        "value": value, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{workload_name}, {W}x{H}, {spp} spp per step ({spp * args.steps} spp in the timed region)",
-                   "paths_per_step_per_gpu": n_pixels * spp, "partition": "sample-index slices per GPU, film all-reduce at the end",
-                   "scene_build_s": build_s},
+    flops_per_launch = None
+    if counters:
+        waves = counters.get("waves", 0)
+        lanes = counters.get("active_lanes_per_valu", 64.0)
+        per_wave = (2 * counters.get("fma_f64_per_wave", 0) + counters.get("mul_f64_per_wave", 0) +
+                    counters.get("add_f64_per_wave", 0) + counters.get("trans_f64_per_wave", 0))
+        launches = counters.get("launches")
+        if launches:
+            flops_per_launch = per_wave * lanes * waves / launches
+        valu = {"occupancy_waves_per_simd": counters.get("waves_per_simd"),
+                "simd_issue_busy": counters.get("simd_valu_busy"),
+                "valu_share_of_wave_time": counters.get("valu_share_of_wave_time"),
+                "wait_share_of_wave_time": counters.get("wait_share_of_wave_time"),
+                "active_lanes_per_instruction": lanes,
+                "valu_instructions_per_wave": counters.get("valu_per_wave"),
+                "f64_flops_per_launch": flops_per_launch, "source": counters_source}
+    if not traverse and flops_per_launch and ms_per_launch > 0:
+        # k_bounce issues fp64 vector instructions most of the time and moves a third of what HBM could: its roof is
+        # the fp64 vector rate
+        achieved = flops_per_launch / (ms_per_launch * 1e-3) / 1e12
+        roofline = {"bound": "valu_f64", "kernel": kernel, "achieved": achieved, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / F64_PEAK_TFLOPS, "traffic": traffic}
+    else:
+        # k_traverse (and k_bounce when no counter file is at hand): against HBM.  `achieved` is the algorithmic
+        # byte count, which for k_traverse includes node and triangle fetches the caches serve; the measured HBM
+        # bytes per launch are `traffic`, and hbm.measured_GBps is what HBM actually delivered
+        roofline = {"bound": "hbm", "kernel": kernel, "achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": algorithmic_gbs / HBM_PEAK_GBS, "traffic": traffic}
+    roofline.update({"hbm": hbm, "valu": valu, "ms_per_launch": ms_per_launch, "launches": int(d_launches),
+                     "profiled_steps": profiled["steps"],
+                     "device_ms": {"k_bounce": fam["k_bounce"][0], "k_bin": fam["k_bin"][0],
+                                   "k_traverse": fam["k_traverse"][0], "other": other_ms[0]},
+                     "vertices_by_class": {CLASS_NAMES[c]: int(st.class_vertices[c]) for c in range(8) if st.class_vertices[c]}})
+    partition = {"samples": "sample-index slices per GPU, film all-reduce at the end",
+                 "tiles": "interleaved 8-row bands per GPU (the frame is n_gpus times as tall), films gathered at the end"}[args.partition]
+    record = {
+        "value": value, "unit": "Mpaths/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "config": {"workload": f"{workload_name}, {W}x{H}, {spp} spp per step ({spp * steps} spp in the timed region)",
+                   "paths_per_step_per_gpu": own_pixels * spp, "partition": partition, "scene_build_s": build_s},
         "rays": {"Grays_per_s": (st.extension_rays + st.shadow_rays) * world / elapsed / 1e9,
                  "extension_rays_per_path": st.extension_rays / max(st.paths, 1),
                  "shadow_rays_per_path": st.shadow_rays / max(st.paths, 1),
@@ -281,34 +350,80 @@ def main():
                  "algorithmic_bytes_per_path": st.algorithmic_bytes / max(st.paths, 1),
                  "traversed_rays_per_path": st.traversed_rays / max(st.paths, 1),
                  "nodes_per_traversed_ray": st.nodes_visited / max(st.traversed_rays, 1),
-                 "triangles_per_traversed_ray": st.triangles_tested / max(st.traversed_rays, 1)},
+                 "triangles_per_traversed_ray": st.triangles_tested / max(st.traversed_rays, 1),
+                 "traversal_stack_overflows": int(st.stack_overflows)},
         "roofline": roofline,
     }
-    if args.denoise and not distributed:
-        # the reference's shipped pipeline (denoising.json: median 3x3 threshold 0.5, then 4 a-trous iterations) on the
-        # rendered film, device to device; bytes: 48 B/pixel for the median, 96 B/pixel per a-trous iteration
-        tasks = pt.make_denoise_tasks(scenes_default_pipeline())
-        scratch = pt.Film(W, H)
+    return record, host_scene, scene, film
+
+
+def denoise_record(pt, film, width, height):
+    """The reference's shipped pipeline (denoising.json: median 3x3 threshold 0.5, then 4 a-trous iterations) on the
+    rendered film, device to device.  Algorithmic bytes: 48 B/pixel for the median (image in, image out) and 96 B/pixel
+    per a-trous iteration (image, position, normal in; image out), fp64."""
+    tasks = pt.make_denoise_tasks(scenes_default_pipeline())
+    scratch = pt.Film(width, height)
+    pt.denoise_film(tasks, film, scratch)
+    pt.sync()
+    reps = 10
+    t1 = time.perf_counter()
+    for _ in range(reps):
         pt.denoise_film(tasks, film, scratch)
-        pt.sync()
-        reps = 10
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            pt.denoise_film(tasks, film, scratch)
-        pt.sync()
-        dt = (time.perf_counter() - t1) / reps
-        out["denoise"] = {"pipeline": "median 3x3 + a-trous x4 (the reference's denoising.json)", "ms_per_frame": dt * 1e3,
-                          "Mpixels_per_s": n_pixels / dt / 1e6, "algorithmic_GBps": n_pixels * (48 + 4 * 96) / dt / 1e9}
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    pt.sync()
+    dt = (time.perf_counter() - t1) / reps
+    n_pixels = width * height
+    gbs = n_pixels * (48 + 4 * 96) / dt / 1e9
+    return {"pipeline": "median 3x3 + a-trous x4 (the reference's denoising.json)", "ms_per_frame": dt * 1e3,
+            "Mpixels_per_s": n_pixels / dt / 1e6,
+            "roofline": {"bound": "hbm", "kernel": "ptk::k_atrous", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS,
+                         "note": "whole pipeline (5 launches) over its algorithmic bytes; per-kernel times in profiles/"}}
+
+
+def main():
+    args = parse_args()
+    ds = Distributed()
+    import pathtracing_amd as pt
+
+    pt.init(ds.local_rank)
+    if args.tail_records >= 0:
+        pt.set_option("tail_records", args.tail_records)
+    for item in args.option:
+        name, _, value = item.partition("=")
+        pt.set_option(name, int(value))
+    code = sources_hash()
+    record, host_scene, scene, film = run_workload(pt, args, ds, args.workload, args.width, args.height, args.spp_per_step,
+                                                   args.steps, args.warmup, code)
+    out = {
+        "metric": "Mpaths/s (whole node) at 1080p, scenes/example + 1M-tri mesh, 1/2/4/8 GPUs",
+        "value": record["value"], "unit": "Mpaths/s", "n_gpus": ds.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": record["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic", "config": record["config"], "rays": record["rays"],
+        "roofline": record["roofline"], "device_library_sources": code,
+    }
+    if ds.rank == 0 and not args.no_cpu_baseline and ds.world == 1:
         threads = args.cpu_threads or min(16, os.cpu_count() or 1)
-        out["cpu_baseline"] = cpu_baseline(host_scene, args, threads)
-        out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-    elif rank == 0:
+        out["cpu_baseline"] = cpu_baseline(host_scene, args.width, args.height, args.seed, threads)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    elif ds.rank == 0:
         out["cpu_baseline"] = None
-    if rank == 0:
+    del scene, film, host_scene
+    if not args.only_headline and args.workload == "example":
+        # the other half of the metric: the 1,048,576-triangle mesh scene, same frame size, same partition
+        mesh, _, mesh_scene, mesh_film = run_workload(pt, args, ds, "mesh", args.width, args.height, args.spp_per_step,
+                                                      args.mesh_steps, 2, code)
+        out["mesh"] = mesh
+        del mesh_scene, mesh_film
+        if not ds.on:
+            # benchmark configuration 5: a frame of the scattering-medium scene, then the denoising pipeline on the GPU
+            cloud, _, cloud_scene, cloud_film = run_workload(pt, args, ds, "cloud", args.width, args.height, args.spp_per_step,
+                                                             4, 1, code)
+            out["denoise"] = denoise_record(pt, cloud_film, args.width, args.height)
+            out["denoise"]["frame"] = {"workload": cloud["config"]["workload"], "Mpaths_per_s": cloud["value"]}
+            del cloud_scene, cloud_film
+    if ds.rank == 0:
         print(json.dumps(out))
-    if distributed:
-        dist.destroy_process_group()
+    ds.close()
 
 
 if __name__ == "__main__":

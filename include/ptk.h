@@ -266,6 +266,14 @@ int ptk_film_device_pointers(PtkFilm* film, double** image, double** position, d
  * scene's device. */
 int ptk_render(PtkScene* scene, PtkFilm* film, const PtkRenderJob* job);
 
+/* ptk_render for a job whose pixels are not one contiguous run but bands: runs of `band_pixels` pixels that begin
+ * `band_stride` pixels apart, the first at job->start_idx; job->number_of_pixels counts the pixels of all bands
+ * together (the last band may be shorter).  With band_pixels = rows * W and band_stride = n_gpus * rows * W these are
+ * the interleaved row bands one GPU of n_gpus owns, rendered as one job.  The reference's scheduler deals out
+ * contiguous pixel ranges to threads (app/pathtracer.cpp:337-354); every (pixel, sample) has its own random stream
+ * here, so a pixel's result does not depend on the job that contains it. */
+int ptk_render_bands(PtkScene* scene, PtkFilm* film, const PtkRenderJob* job, int64_t band_pixels, int64_t band_stride);
+
 /* Same, on caller-owned host buffers (the mmap'd temp/raw_*.dat files): uploads the
  * pixel range, renders, downloads, and returns when the buffers are updated. */
 int ptk_render_host(PtkScene* scene, const PtkRenderJob* job, double* image, double* position, double* normal,

@@ -289,6 +289,11 @@ class DeviceScene:
     def render(self, film, job):
         _check_dev(device_lib().ptk_render(self._handle, film._handle, C.byref(job)))
 
+    def render_bands(self, film, job, band_pixels, band_stride):
+        """render() for a job made of runs of `band_pixels` pixels that begin `band_stride` pixels apart (the
+        interleaved row bands of one GPU, see distributed.band_job); job.number_of_pixels counts all of them."""
+        _check_dev(device_lib().ptk_render_bands(self._handle, film._handle, C.byref(job), int(band_pixels), int(band_stride)))
+
     def render_host(self, job, image, position, normal, counters):
         n = self.n_pixels
         if image.size != 3 * n or position.size != 3 * n or normal.size != 3 * n or counters.size != n:

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(BatchParams b, SampleResul
             sum[8] += s2.y;
         }
         const double n_add = static_cast<double>(b.n_samples);
-        const size_t idx = static_cast<size_t>(b.start_idx) + p;
+        const size_t idx = batch_pixel(b, p);
         const double n_prev = static_cast<double>(pixel_counters[idx]);
         for (int j = 0; j < 3; j++) {
             image[3 * idx + j] = (image[3 * idx + j] * n_prev + (sum[j] / n_add) * n_add) / (n_prev + n_add);
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(BLOCK) void k_primary(DevScene sc, BatchParams b, i
     __shared__ StackEntry lds_stack[LDS_STACK_DEPTH * BLOCK];
     PTK_TRAVERSAL_STACK(st, lds_stack, sc);
     for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < b.n_pixels; p += gridDim.x * BLOCK) {
-        const uint32_t pixel = static_cast<uint32_t>(b.start_idx) + p;
+        const uint32_t pixel = batch_pixel(b, p);
         Rng rng{rng_key(b.seed, pixel, b.sample_offset), 0};
         V3 org, dir;
         camera_ray(sc, pixel, rng, org, dir);

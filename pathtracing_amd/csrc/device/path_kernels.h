@@ -64,9 +64,16 @@ PTK_DEV TraversalStack make_stack(StackEntry* lds, StackEntry* spill, uint32_t* 
     StackEntry st##_spill[SPILL_STACK_DEPTH];     \
     TraversalStack st = make_stack(lds_array, st##_spill, (scene).stack_overflows)
 
+// Linear pixel index (row * W + x) of pixel p of a batch.
+PTK_DEV uint32_t batch_pixel(const BatchParams& b, uint32_t p) {
+    if (b.band_pixels == 0) return static_cast<uint32_t>(b.start_idx) + p;
+    const uint32_t k = b.band_first + p, band = k / b.band_pixels;
+    return static_cast<uint32_t>(b.start_idx) + band * b.band_stride + (k - band * b.band_pixels);
+}
+
 PTK_DEV void sample_coordinates(const BatchParams& b, uint32_t sid, uint32_t& pixel, uint32_t& sample) {
     uint32_t s = sid / b.n_pixels;
-    pixel = static_cast<uint32_t>(b.start_idx) + (sid - s * b.n_pixels);
+    pixel = batch_pixel(b, sid - s * b.n_pixels);
     sample = b.sample_offset + s;
 }
 

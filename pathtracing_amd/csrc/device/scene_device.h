@@ -236,12 +236,15 @@ constexpr uint32_t MEDIUM_NONE = 0x7FFFu;
 constexpr uint8_t CLASS_DONE = 0xFF; // the path ended and its radiance is in the results
 
 struct BatchParams {
-    int64_t start_idx;    // first pixel
+    int64_t start_idx;    // first pixel of the batch (banded jobs: of the job)
     uint32_t n_pixels;    // pixels in this batch
     uint32_t n_samples;   // samples per pixel in this batch
     uint32_t sample_offset;
     uint32_t n_paths;     // n_pixels * n_samples
     uint64_t seed;
+    // Banded jobs (ptk_render_bands): the job's pixels are runs of band_pixels pixels that begin band_stride pixels
+    // apart; pixel p of the batch is pixel band_first + p of the job.  band_pixels == 0: one contiguous run.
+    uint32_t band_pixels, band_stride, band_first, _pad;
 };
 
 // A bounce's records are binned by class without atomics: k_bin_count leaves per-block class

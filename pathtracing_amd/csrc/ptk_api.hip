@@ -484,8 +484,9 @@ int check_job(const PtkScene* s, const PtkRenderJob* job, const char* who) {
 }
 
 // Splits a job into batches of whole pixels and calls `after_batch(batch, first_pixel_of_batch_in_job)`.
+// band_pixels > 0: the job's pixels are runs of that many pixels, band_stride pixels apart (ptk_render_bands).
 template<typename F>
-int for_each_batch(PtkScene* s, const PtkRenderJob* job, F&& after_batch) {
+int for_each_batch(PtkScene* s, const PtkRenderJob* job, F&& after_batch, uint32_t band_pixels = 0, uint32_t band_stride = 0) {
     if (job->number_of_pixels == 0 || job->number_of_samples == 0) return PTK_OK;
     const int64_t per_batch = std::max<int64_t>(1, s->max_paths / job->number_of_samples);
     const int64_t batch_pixels = std::min<int64_t>(per_batch, job->number_of_pixels);
@@ -493,7 +494,10 @@ int for_each_batch(PtkScene* s, const PtkRenderJob* job, F&& after_batch) {
     if (rc != PTK_OK) return rc;
     for (int64_t p = 0; p < job->number_of_pixels; p += batch_pixels) {
         BatchParams b{};
-        b.start_idx = job->start_idx + p;
+        b.start_idx = band_pixels ? job->start_idx : job->start_idx + p;
+        b.band_pixels = band_pixels;
+        b.band_stride = band_stride;
+        b.band_first = band_pixels ? static_cast<uint32_t>(p) : 0u;
         b.n_pixels = static_cast<uint32_t>(std::min<int64_t>(batch_pixels, job->number_of_pixels - p));
         b.n_samples = static_cast<uint32_t>(job->number_of_samples);
         b.sample_offset = static_cast<uint32_t>(job->sample_offset);
@@ -1176,6 +1180,39 @@ int ptk_render(PtkScene* s, PtkFilm* film, const PtkRenderJob* job) {
         s->stats.algorithmic_bytes += ACCUMULATE_BYTES_PER_PATH * b.n_paths;
         return static_cast<int>(PTK_OK);
     });
+    PTK_GUARD_END
+}
+
+int ptk_render_bands(PtkScene* s, PtkFilm* film, const PtkRenderJob* job, int64_t band_pixels, int64_t band_stride) {
+    PTK_GUARD_BEGIN
+    if (!s || !job) return fail(PTK_ERR_INVALID, "ptk_render_bands: null argument");
+    if (band_pixels < 1 || band_stride < band_pixels || band_stride > (int64_t(1) << 31))
+        return fail(PTK_ERR_INVALID, "ptk_render_bands: need 1 <= band_pixels <= band_stride");
+    if (job->number_of_pixels < 0 || job->start_idx < 0) return fail(PTK_ERR_INVALID, "ptk_render_bands: negative pixel range");
+    if (job->number_of_pixels > 0) { // the last pixel of the last (possibly partial) band must lie inside the image
+        const int64_t last = job->number_of_pixels - 1;
+        const int64_t last_pixel = job->start_idx + (last / band_pixels) * band_stride + last % band_pixels;
+        if (last_pixel >= static_cast<int64_t>(s->settings.width) * s->settings.height)
+            return fail(PTK_ERR_INVALID, "ptk_render_bands: pixel range outside the image");
+    }
+    PtkRenderJob contiguous = *job; // the remaining checks are those of a contiguous job of as many pixels
+    contiguous.start_idx = 0;
+    int rc = check_job(s, &contiguous, "ptk_render_bands");
+    if (rc != PTK_OK) return rc;
+    if (!film || film->width != s->settings.width || film->height != s->settings.height)
+        return fail(PTK_ERR_INVALID, "ptk_render_bands: film size does not match the scene");
+    if (film->ctx != s->ctx) return fail(PTK_ERR_INVALID, "ptk_render_bands: the film and the scene live on different devices");
+    if ((rc = use(s->ctx)) != PTK_OK) return rc;
+    const hipStream_t g_stream = s->ctx->stream;
+    return for_each_batch(
+        s, job,
+        [&](const BatchParams& b, int64_t) {
+            launch_accumulate(g_stream, b, s->results, film->image, film->position, film->normal, film->counters);
+            HIP_TRY(hipGetLastError());
+            s->stats.algorithmic_bytes += ACCUMULATE_BYTES_PER_PATH * b.n_paths;
+            return static_cast<int>(PTK_OK);
+        },
+        static_cast<uint32_t>(band_pixels), static_cast<uint32_t>(band_stride));
     PTK_GUARD_END
 }
 

@@ -31,6 +31,15 @@ def row_bands(rank, world, width, height, band_rows=8):
     return jobs
 
 
+def band_job(rank, world, width, height, band_rows=8):
+    """The row bands of `rank` (see row_bands) as one banded job for DeviceScene.render_bands / ptk_render_bands:
+    (start_idx, number_of_pixels, band_pixels, band_stride)."""
+    runs = row_bands(rank, world, width, height, band_rows)
+    if not runs:
+        return 0, 0, band_rows * width, world * band_rows * width
+    return runs[0][0], sum(n for _, n in runs), band_rows * width, world * band_rows * width
+
+
 def combine_films(image, position, normal, counters, group=None):
     """In-place weighted mean of per-rank films: each of `image`, `position`, `normal` is a running
     mean over `counters` samples per pixel ([H*W*3] / [H*W] tensors on any device).  Afterwards every

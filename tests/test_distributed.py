@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 import pathtracing_amd as pt
 from pathtracing_amd import scenes
-from pathtracing_amd.distributed import combine_films, row_bands, sample_slice
+from pathtracing_amd.distributed import band_job, combine_films, row_bands, sample_slice
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -37,6 +37,16 @@ def test_row_bands_cover_all_pixels_exactly_once():
                 for start, n in row_bands(r, world, w, h, band):
                     seen[start:start + n] += 1
             assert (seen == 1).all()
+
+
+def test_band_jobs_describe_the_same_pixels_as_the_row_bands():
+    for world in (1, 2, 3, 8):
+        for (w, h, band) in [(64, 48, 8), (37, 29, 8), (16, 5, 2), (8, 3, 8)]:
+            for r in range(world):
+                start, n, band_pixels, stride = band_job(r, world, w, h, band)
+                pixels = [start + (k // band_pixels) * stride + k % band_pixels for k in range(n)]
+                want = [p for s0, m in row_bands(r, world, w, h, band) for p in range(s0, s0 + m)]
+                assert pixels == want
 
 
 def _worker(rank, world, port, scene_dir, mode, out_dir):

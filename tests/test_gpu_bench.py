@@ -8,7 +8,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--width", "320", "--height", "180", "--steps", "5", "--warmup", "1", "--cpu-threads", "4"]
+SMALL = ["--width", "320", "--height", "180", "--steps", "5", "--warmup", "1", "--cpu-threads", "4", "--mesh-lon", "64",
+         "--mesh-lat", "33", "--mesh-steps", "2", "--tail-records", "0"]  # tail_records 0: every bounce through k_bounce / k_traverse
 
 
 def check_line(out, n_gpus):
@@ -20,11 +21,19 @@ def check_line(out, n_gpus):
     assert d["n_gpus"] == n_gpus and d["steps"] == 5 and d["warmup"] == 1
     assert d["unit"] == "Mpaths/s" and d["value"] > 0 and d["scaling"] == "weak" and d["dtype"] == "f64"
     assert d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"]
-    r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    check_roofline(d["roofline"])
+    m = d["mesh"]  # the other half of the metric, measured in the same process
+    assert m["value"] > 0 and m["unit"] == "Mpaths/s" and "triangle OBJ mesh" in m["config"]["workload"]
+    assert m["rays"]["nodes_per_traversed_ray"] > 0 and m["rays"]["traversal_stack_overflows"] == 0
+    check_roofline(m["roofline"])
+    return d
+
+
+def check_roofline(r):
+    assert (r["bound"], r["unit"], r["peak"]) in (("hbm", "GB/s", 8000.0), ("valu_f64", "TFLOP/s", 78.6))
     assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["kernel"].startswith("ptk::k_") and r["profiled_steps"] >= 1
-    return d
+    assert r["hbm"]["algorithmic_GBps"] > 0 and r["ms_per_launch"] > 0
 
 
 def test_default_path_prints_the_contract_line():
@@ -33,6 +42,7 @@ def test_default_path_prints_the_contract_line():
     d = check_line(r.stdout, 1)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 4 and c["value"] > 0 and c["unit"] == "Mpaths/s" and c["sample"]
+    assert d["denoise"]["ms_per_frame"] > 0 and d["denoise"]["roofline"]["bound"] == "hbm"
 
 
 def test_multi_gpu_path_with_one_rank():
@@ -43,3 +53,13 @@ def test_multi_gpu_path_with_one_rank():
     assert r.returncode == 0, r.stderr[-2000:]
     d = check_line(r.stdout, 1)
     assert d["cpu_baseline"] is None
+
+
+def test_tile_partition_with_one_rank():
+    env = dict(os.environ, PTK_BENCH_FORCE_DISTRIBUTED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29518", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline", "--partition", "tiles"] + SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = check_line(r.stdout, 1)
+    assert "bands" in d["config"]["partition"]

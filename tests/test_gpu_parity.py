@@ -351,6 +351,31 @@ def test_degenerate_jobs_and_scenes(tmp_path, ob):
         dev.render(film, pt.make_job(32 * 24 - 1, 2, 1, 0, 1))
 
 
+@pytest.mark.parametrize("name", ["example", "mesh_gold", "cloud"])
+def test_interleaved_band_jobs_reproduce_the_frame(scene_dirs, name):
+    """The tile half of the multi-GPU split on one GPU: the interleaved row bands of each of three would-be ranks,
+    rendered as one banded job per rank (ptk_render_bands), give the film of the single whole-frame job bit for bit,
+    also when the path pool is small enough to cut a rank's job into batches in the middle of a band."""
+    from pathtracing_amd.distributed import band_job
+    hs = pt.load_scene_directory(scene_dirs[name])
+    W, H = hs.settings.width, hs.settings.height
+    dev = pt.DeviceScene(hs)
+    whole = pt.Film(W, H)
+    dev.render(whole, pt.make_job(0, W * H, 5, 2, 99))
+    want = whole.download()
+    for in_flight in (0, 1500):
+        banded_scene = pt.DeviceScene(hs, max_paths_in_flight=in_flight)
+        film = pt.Film(W, H)
+        for rank in range(3):
+            start, n, band_pixels, stride = band_job(rank, 3, W, H, band_rows=4)
+            banded_scene.render_bands(film, pt.make_job(start, n, 5, 2, 99), band_pixels, stride)
+        got = film.download()
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b), in_flight
+    with pytest.raises(pt.PtkError):  # the last band would leave the image
+        dev.render_bands(whole, pt.make_job(W * (H - 2), 4 * W, 1, 0, 0), 4 * W, 12 * W)
+
+
 def test_record_staging_through_lds_delivers_every_record():
     """k_bounce prefetches its records with asynchronous loads straight into LDS and reads them back behind
     hand-written wait counts (request_record / staged_record in path_kernels.h).  The library's self-test pushes
