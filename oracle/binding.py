@@ -69,6 +69,10 @@ REF_PROTOTYPES = {
     "ref_rotate": (None, [d3, C.c_double, C.c_double, C.c_double, d3]),
     "ref_refract": (None, [d3, d3, C.c_double, d3]),
     "ref_solve_quadratic": (C.c_int, [C.c_double, C.c_double, dptr]),
+    "ref_probe_load_object_model": (C.c_long, [C.c_char_p, C.c_int, C.c_int, dptr, dptr, C.c_double, C.c_long, dptr, dptr, dptr,
+                                               C.POINTER(C.c_uint8), C.c_char_p, C.c_int]),
+    "ref_probe_create_value_map": (C.c_long, [C.c_char_p, C.c_int, C.c_int, C.c_long, dptr, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                              C.c_char_p, C.c_int]),
 }
 
 _oracle = None
@@ -200,6 +204,45 @@ class RefScene(_SceneBase):
         image, pos, nrm = np.zeros(shape), np.zeros(shape), np.zeros(shape)
         self._call("render", self._handle, int(threads), _dp(image), _dp(pos), _dp(nrm))
         return image, pos, nrm
+
+
+def ref_load_object_model(path, smooth=False, center=None, orientation=None, size=None):
+    """The reference's own load_object_model (src/objectunion.cpp:425-443) on an OBJ file, with the transform flags
+    load_object (src/scene.cpp:399-412) derives from which JSON keys are present; `orientation` is {X, Y, Z} in
+    degrees.  Returns (vertices [n, 9], uv [n, 6], normals [n, 9], smooth [n]) in the order of the reference's
+    triangle array, or the reference's error message as a string, or None when the reference would go on to
+    dereference a null triangle."""
+    lib = ref_lib()
+    flags = (1 if center is not None else 0) | (2 if orientation is not None else 0) | (4 if size is not None else 0)
+    c = np.array(center if center is not None else [0, 0, 0], dtype=np.float64)
+    o = np.array([orientation["Y"], orientation["Z"], orientation["X"]] if orientation is not None else [0, 0, 0], dtype=np.float64)
+    err = C.create_string_buffer(512)
+    args = (os.fsencode(path), int(bool(smooth)), flags, _dp(c), _dp(o), float(size if size is not None else 0.0))
+    n = lib.ref_probe_load_object_model(*args, -1, None, None, None, None, err, 512)
+    if n == -1:
+        return err.value.decode()
+    if n == -2:
+        return None
+    v, t, nr = np.zeros((max(n, 1), 9)), np.zeros((max(n, 1), 6)), np.zeros((max(n, 1), 9))
+    sm = np.zeros(max(n, 1), dtype=np.uint8)
+    got = lib.ref_probe_load_object_model(*args, n, _dp(v), _dp(t), _dp(nr), sm.ctypes.data_as(C.POINTER(C.c_uint8)), err, 512)
+    if got == -1:
+        return err.value.decode()
+    assert got == n
+    return v[:n], t[:n], nr[:n], sm[:n]
+
+
+def ref_create_value_map(path, channels, gamma_correct=False):
+    """The reference's create_value_map_1D / _3D (src/valuemap.cpp:54-100): (data [h, w, channels]) or its error."""
+    lib = ref_lib()
+    err = C.create_string_buffer(512)
+    w, h = C.c_int(), C.c_int()
+    n = lib.ref_probe_create_value_map(os.fsencode(path), channels, int(bool(gamma_correct)), 0, None, C.byref(w), C.byref(h), err, 512)
+    if n < 0:
+        return err.value.decode()
+    data = np.zeros(max(n, 1))
+    lib.ref_probe_create_value_map(os.fsencode(path), channels, int(bool(gamma_correct)), n, _dp(data), C.byref(w), C.byref(h), err, 512)
+    return data[:n].reshape(h.value, w.value, channels)
 
 
 def oracle_denoise(tasks, image, position, normal):

@@ -2,8 +2,10 @@
 //
 // This file is compiled together with the reference's own sources, taken from where they
 // lie (oracle/Makefile; nothing of the reference is copied into this repository), into
-// oracle/_ref/libref.so.  It exists only in the build container: the reference cannot
-// travel, so what it produces is committed as fixtures under tests/golden/.
+// oracle/_ref/libref.so.  It can only be built where the reference's sources are (the build
+// container): the sources do not travel, so what the library produces is committed as
+// fixtures under tests/golden/ (the built library itself may be carried along and used as a
+// checker or a CPU baseline where it is present; nothing depends on it being there).
 //
 // What it adds to the reference code:
 //   * scene construction from the flat PtkSceneDesc through the reference's public

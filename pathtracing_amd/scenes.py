@@ -208,22 +208,24 @@ def write_bumpy_sphere_obj(path, n_lon, n_lat, seed=7, bump=0.08, quads=True):
         c = ((i + 1) * cols + j + 2).ravel()
         d = ((i + 1) * cols + j + 1).ravel()
         rows = i.ravel()
-        lines = []
-        for k in range(a.size):
-            A, B, Cc, D = a[k], b[k], c[k], d[k]
-            if rows[k] == 0:               # north-pole fan: one triangle
-                lines.append("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (A, A, A, Cc, Cc, Cc, D, D, D))
-            elif rows[k] == n_lat - 1:     # south-pole fan
-                lines.append("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (A, A, A, B, B, B, D, D, D))
-            elif quads:
-                lines.append("f %d/%d/%d %d/%d/%d %d/%d/%d %d/%d/%d\n" % (A, A, A, B, B, B, Cc, Cc, Cc, D, D, D))
-            else:
-                lines.append("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (A, A, A, B, B, B, Cc, Cc, Cc))
-                lines.append("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (A, A, A, Cc, Cc, Cc, D, D, D))
-            if len(lines) >= 65536:
-                f.write("".join(lines))
-                lines = []
-        f.write("".join(lines))
+
+        def write_faces(fmt, select, *corners):  # one line per selected cell, corner indices repeated for v/vt/vn
+            cols_ = [np.repeat(c[select][:, None], 3, axis=1) for c in corners]
+            table = np.concatenate(cols_, axis=1).tolist()
+            for lo in range(0, len(table), 262144):
+                f.write("".join([fmt % tuple(r) for r in table[lo:lo + 262144]]))
+
+        tri = "f %d/%d/%d %d/%d/%d %d/%d/%d\n"
+        north, south = rows == 0, rows == n_lat - 1
+        inner = ~(north | south)
+        write_faces(tri, north, a, c, d)                       # north-pole fan: one triangle per cell
+        if quads:
+            write_faces("f %d/%d/%d %d/%d/%d %d/%d/%d %d/%d/%d\n", inner, a, b, c, d)
+        else:
+            ai, bi, ci, di = a[inner], b[inner], c[inner], d[inner]
+            two = np.stack([np.stack([ai, bi, ci], 1), np.stack([ai, ci, di], 1)], 1).reshape(-1, 3)
+            write_faces(tri, slice(None), two[:, 0], two[:, 1], two[:, 2])
+        write_faces(tri, south, a, b, d)                       # south-pole fan
     return 2 * n_lon * (n_lat - 1)
 
 

@@ -55,9 +55,14 @@ def build_scene(name, directory):
 
 
 def main():
-    """Without arguments regenerates everything; with scene names, only their primary_/samples_ files."""
+    """Without arguments regenerates everything; with scene names, only their primary_/samples_ files; with
+    `converged`, only the high-sample-count mean images."""
     tmp = tempfile.mkdtemp(prefix="ptk_golden_")
     only = sys.argv[1:]
+    if only == ["converged"]:
+        return converged(tmp)
+    if only == ["loaders"]:
+        return loaders(tmp)
     for name in (only or SCENES):
         d = os.path.join(tmp, name)
         spp = build_scene(name, d)
@@ -136,15 +141,55 @@ def main():
     h["quad_b"], h["quad_c"], h["quad_root"] = b, c, roots
     np.savez_compressed(os.path.join(HERE, "helpers.npz"), **h)
 
-    # converged image, unseeded reference at high sample count (several minutes on one thread)
-    d = os.path.join(tmp, "converged")
-    spp = int(os.environ.get("PTK_GOLDEN_SPP", "2048"))
-    scenes.cornell_example(d, WIDTH=48, HEIGHT=32, samples_per_pixel=spp, samples_per_iteration=64)
-    hs = pt.load_scene_directory(d)
-    image, pos, nrm = ob.RefScene(hs).render(1)
-    np.savez_compressed(os.path.join(HERE, "converged_example.npz"), spp=spp, image=image.astype(np.float32))
-    print("converged ok", image.mean())
+    loaders(tmp)
+    converged(tmp)
 
+
+def loaders(tmp):
+    """What the reference's own OBJ and .map loaders make of the inputs in loader_cases.py.  Triangles are stored in
+    a canonical order (rows sorted): the reference's array has been re-ordered by the root of its hierarchy."""
+    import loader_cases
+    obj_paths, map_paths = loader_cases.write_inputs(os.path.join(tmp, "loader_inputs"))
+    out = {}
+    for name, key, params in loader_cases.OBJ_CASES:
+        path = obj_paths[key] if key else os.path.join(tmp, "loader_inputs", "does_not_exist.obj")
+        r = ob.ref_load_object_model(path, params.get("enable_smooth_shading", False), params.get("center"),
+                                     params.get("orientation"), params.get("size"))
+        assert r is not None, name  # an input the reference cannot digest does not belong in the cases
+        if isinstance(r, str):
+            out[name + "_error"] = np.array(r.replace(path, "<file>"))
+            print("obj", name, "error:", r)
+            continue
+        v, t, n, smooth = r
+        rows = np.concatenate([v, t, n, smooth[:, None].astype(np.float64)], axis=1)
+        rows = rows[np.lexsort(rows.T[::-1])]
+        out[name + "_triangles"] = rows
+        print("obj", name, len(rows), "triangles")
+    np.savez_compressed(os.path.join(HERE, "loader_obj.npz"), **out)
+    out = {}
+    for name, _, channels, gamma in loader_cases.MAP_CASES:
+        r = ob.ref_create_value_map(map_paths[name], channels, gamma)
+        if isinstance(r, str):
+            out[name + "_error"] = np.array(r.replace(map_paths[name], "<file>"))
+            print("map", name, "error:", r)
+        else:
+            out[name + "_data"] = r
+            print("map", name, r.shape)
+    np.savez_compressed(os.path.join(HERE, "loader_map.npz"), **out)
+
+
+def converged(tmp):
+    """Mean images of the unseeded reference at high sample counts (minutes on one thread each): the statistical pin of
+    the counter-based random streams.  PTK_GOLDEN_SPP scales the sample counts (default 16384 for the example scene,
+    half of that for the scattering-medium scene)."""
+    spp = int(os.environ.get("PTK_GOLDEN_SPP", "16384"))
+    for name, builder, kwargs, n in (("example", scenes.cornell_example, {}, spp), ("cloud", scenes.cloud_box, {}, spp // 2)):
+        d = os.path.join(tmp, "converged_" + name)
+        builder(d, WIDTH=48, HEIGHT=32, samples_per_pixel=n, samples_per_iteration=64, **kwargs)
+        hs = pt.load_scene_directory(d)
+        image, pos, nrm = ob.RefScene(hs).render(1)
+        np.savez_compressed(os.path.join(HERE, f"converged_{name}.npz"), spp=n, image=image.astype(np.float32))
+        print("converged", name, "ok", image.mean())
 
 if __name__ == "__main__":
     main()

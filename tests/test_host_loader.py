@@ -228,3 +228,83 @@ def test_mutated_scene_directories_load_or_fail_with_a_message():
     run = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_loader.py"), "0", "120"], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     assert "refused" in run.stdout.splitlines()[-1]
+
+
+# ---- the loaders against the reference's own --------------------------------------------------------------------
+# tests/golden/loader_obj.npz and loader_map.npz hold what the reference's load_object_model and create_value_map
+# (src/objectunion.cpp:425-443, src/valuemap.cpp:54-100) made of the inputs in tests/golden/loader_cases.py
+# (generated by tests/golden/make_golden.py from oracle/_ref/libref.so).  This repository's loader must produce the same
+# numbers, bit for bit, and fail where the reference fails.
+import sys  # noqa: E402
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import loader_cases  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def loader_inputs(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("loader_inputs"))
+    return (d,) + loader_cases.write_inputs(d)
+
+
+@pytest.mark.parametrize("name,key,params", loader_cases.OBJ_CASES, ids=[c[0] for c in loader_cases.OBJ_CASES])
+def test_obj_loader_matches_the_reference_loader(loader_inputs, name, key, params):
+    directory, obj_paths, _ = loader_inputs
+    golden = np.load(os.path.join(GOLDEN, "loader_obj.npz"))
+    file = os.path.basename(obj_paths[key]) if key else "does_not_exist.obj"
+    obj = {"name": "mesh", "type": "Object", "subtype": "ObjectUnion", "parameters": dict(file=file, material="m", **params)}
+    text = json.dumps(_scene_with([obj]))
+    if name + "_error" in golden:  # the reference throws: so must the loader (the wording is the reference's for a missing file)
+        with pytest.raises(pt.PtkError) as e:
+            pt.HostScene.from_text(text, pt.default_settings(), directory)
+        if "Could not open" in str(golden[name + "_error"]):
+            assert "Could not open file" in str(e.value)
+        return
+    hs = pt.HostScene.from_text(text, pt.default_settings(), directory)
+    d = hs.desc
+    n = d.n_triangles
+    want = golden[name + "_triangles"]
+    assert n == len(want)
+    if n == 0:
+        return
+    v = np.ctypeslib.as_array(d.tri_vertices, shape=(n, 9))
+    uv = np.ctypeslib.as_array(d.tri_uv, shape=(n, 6))
+    nrm = np.ctypeslib.as_array(d.tri_normals, shape=(n, 9)).copy()
+    flags = np.ctypeslib.as_array(d.tri_flags, shape=(n,))
+    smooth = (flags & _ffi.PTK_TRI_SMOOTH) != 0
+    # vertex normals matter for smooth triangles only: a flat one carries its face normal in the reference and
+    # unspecified values here (the device library derives the face normal itself)
+    nrm[~smooth] = 0.0
+    want = want.copy()
+    want[want[:, 24] == 0, 15:24] = 0.0
+    want = want[np.lexsort(want.T[::-1])]
+    assert (uv[(flags & _ffi.PTK_TRI_HAS_UV) == 0] == 0).all()
+    rows = np.concatenate([v, uv, nrm, smooth[:, None].astype(np.float64)], axis=1)
+    rows = rows[np.lexsort(rows.T[::-1])]  # the reference's array is in the order its hierarchy's root sorted it into
+    assert np.array_equal(rows, want), name
+
+
+@pytest.mark.parametrize("name,source,channels,gamma", loader_cases.MAP_CASES, ids=[c[0] for c in loader_cases.MAP_CASES])
+def test_map_loader_matches_the_reference_loader(loader_inputs, name, source, channels, gamma):
+    directory, _, map_paths = loader_inputs
+    golden = np.load(os.path.join(GOLDEN, "loader_map.npz"))
+    kind = "ValueMap1D" if channels == 1 else "ValueMap3D"
+    maps = [scenes._map_file("tex", kind, os.path.basename(map_paths[name]))]
+    material = scenes._material("m", "Diffuse", **({"roughness_map": "tex"} if channels == 1 else {"albedo_map": "tex"}))
+    text = json.dumps(_scene_with([scenes._sphere("s", [0, 0, 0], 1, "m")], materials=[material], maps=maps))
+    settings = pt.default_settings()
+    settings.use_gamma_correction = 1 if gamma else 0
+    if name + "_error" in golden:
+        with pytest.raises(pt.PtkError) as e:
+            pt.HostScene.from_text(text, settings, directory)
+        reference_message = str(golden[name + "_error"]).replace("<file>", os.path.basename(map_paths[name]))
+        assert reference_message in str(e.value).replace(directory + os.sep, "")
+        return
+    hs = pt.HostScene.from_text(text, settings, directory)
+    m = hs.desc.maps[0]
+    want = golden[name + "_data"]
+    assert (m.height, m.width, m.dim) == want.shape
+    got = np.ctypeslib.as_array(hs.desc.map_data, shape=(hs.desc.n_map_values,))[m.offset:m.offset + want.size]
+    assert np.array_equal(got.reshape(want.shape), want), name
