@@ -290,7 +290,8 @@ int ptk_reset_stats(PtkScene* scene);
 int ptk_set_profiling(int enabled);
 /* Tuning knobs, by name, process-wide (no counterpart in the reference).  "tail_records": once at most this many paths of a
  * batch are left, one kernel launch follows each of them to its end instead of running three launches per bounce
- * (0 switches that off; default 1048576, upper limit 16777216; scenes with meshes switch at four times the value).  "specialised_kernels": 1 (default) traces a scene with the
+ * (0 switches that off; default 1048576, upper limit 16777216; scenes with meshes switch at four times the value).  "traverse_lanes": 1 (default) walks the hierarchies of queued rays with one
+ * lane per ray; 4 with four lanes per ray, one per child box or triangle (slower as measured).  "specialised_kernels": 1 (default) traces a scene with the
  * kernels compiled for what it contains (no triangles, no texture coordinates, tables small enough for on-chip
  * copies, ...); 0 makes every scene use the general kernels that scenes with many objects get.  Unknown names and
  * values out of range fail with PTK_ERR_INVALID.  Results do not depend on any knob. */

@@ -251,6 +251,125 @@ PTK_DEV void mesh_closest_hit(const DevScene& sc, int32_t bvh_root, int64_t firs
     }
 }
 
+// ---- four lanes per ray --------------------------------------------------------------------------------------
+// k_traverse gives every ray a quad of lanes (lanes 4q .. 4q + 3 of the wave).  At an inner node lane c tests the box
+// of child c; at a leaf lane c tests triangle c.  What a ray's lanes share (the ray, its closest hit, its node, its
+// stack pointer) is kept identically in all four; values cross lanes with DPP quad permutes, which cost no memory
+// access.  All control flow that contains a permute is uniform within a quad.
+template<int CTRL>
+PTK_DEV int quad_perm_i(int v) {
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
+template<int CTRL>
+PTK_DEV float quad_perm_f(float v) {
+    return __int_as_float(quad_perm_i<CTRL>(__float_as_int(v)));
+}
+template<int CTRL>
+PTK_DEV double quad_perm_d(double v) {
+    return __hiloint2double(quad_perm_i<CTRL>(__double2hiint(v)), quad_perm_i<CTRL>(__double2loint(v)));
+}
+// lane c reads lane (c + k) % 4 of its quad
+constexpr int QUAD_ROTATE_1 = 0x39, QUAD_ROTATE_2 = 0x4E, QUAD_ROTATE_3 = 0x93;
+// sum over the quad (in every lane)
+PTK_DEV int quad_sum(int v) {
+    v += quad_perm_i<0xB1>(v); // neighbours swapped: [1, 0, 3, 2]
+    v += quad_perm_i<QUAD_ROTATE_2>(v);
+    return v;
+}
+
+// The ray's stack: one column of LDS per ray, entry d at stack[d * rays_per_block]; all four lanes hold sp.
+struct QuadStack {
+    LdsStackEntry* column;
+    int stride;
+    int sp;
+    uint32_t* overflows;
+};
+
+// Inner node `node` for one ray: lane c tests child c; the children that can hold something closer than t_best are
+// pushed farthest first except the nearest, which is returned (or the next entry of the stack that can still matter,
+// BVH_EMPTY when there is none).  c: the lane's position in its quad.
+PTK_DEV int32_t pop_closer_quad(QuadStack& st, double t_best) {
+    while (st.sp > 0) {
+        st.sp--;
+        const int32_t node = st.column[st.sp * st.stride].node;
+        const float tnear = st.column[st.sp * st.stride].tnear;
+        if (static_cast<double>(tnear) < t_best) return node;
+    }
+    return BVH_EMPTY;
+}
+
+struct SlabRay1 { // per-ray constants of the fp32 slab test (see slab_ray)
+    float nox, noy, noz, ix, iy, iz, px, py, pz;
+};
+PTK_DEV SlabRay1 slab_ray1(const V3& org, const V3& dir, float bound_abs) {
+    const SlabRay r = slab_ray(org, dir, bound_abs);
+    return SlabRay1{r.nox[0], r.noy[0], r.noz[0], r.ix[0], r.iy[0], r.iz[0], r.px[0], r.py[0], r.pz[0]};
+}
+
+PTK_DEV int32_t visit_inner_quad(const BvhNodeQuad* nodes, int32_t node, int c, const SlabRay1& r, double t_best, QuadStack& st) {
+    const float FAR = __builtin_inff();
+    const float4* box = reinterpret_cast<const float4*>(&nodes[node].c[c]);
+    const float4 a = box[0], b = box[1]; // lo.x lo.y lo.z hi.x | hi.y hi.z child pad
+    const int32_t child = __float_as_int(b.z);
+    // the arithmetic of visit_inner, one box per lane
+    const float ax = (a.x + r.nox) * r.ix, bx = (a.w + r.nox) * r.ix;
+    const float ay = (a.y + r.noy) * r.iy, by = (b.x + r.noy) * r.iy;
+    const float az = (a.z + r.noz) * r.iz, bz = (b.y + r.noz) * r.iz;
+    float lo = fmaxf(fmaxf(0.0f, fminf(ax, bx) - r.px), fmaxf(fminf(ay, by) - r.py, fminf(az, bz) - r.pz));
+    float hi = fminf(fmaxf(ax, bx) + r.px, fminf(fmaxf(ay, by) + r.py, fmaxf(az, bz) + r.pz));
+    lo *= 1.0f - 0x1p-21f;
+    hi *= 1.0f + 0x1p-21f;
+    const bool ok = child != BVH_EMPTY && hi >= lo && static_cast<double>(lo) < t_best;
+    const float t = ok ? lo : FAR;
+    // rank of this child among the quad's hits: how many of the others come first (nearer, or as near in a lower lane)
+    const float t1 = quad_perm_f<QUAD_ROTATE_1>(t), t2 = quad_perm_f<QUAD_ROTATE_2>(t), t3 = quad_perm_f<QUAD_ROTATE_3>(t);
+    const int rank = ((t1 < t || (t1 == t && c + 1 >= 4)) ? 1 : 0) + ((t2 < t || (t2 == t && c + 2 >= 4)) ? 1 : 0) +
+                     ((t3 < t || (t3 == t && c + 3 >= 4)) ? 1 : 0);
+    const int n_hit = quad_sum(ok ? 1 : 0);
+    if (n_hit == 0) return pop_closer_quad(st, t_best);
+    // ranks 1 .. n_hit - 1 go to the stack, rank 1 on top
+    if (ok && rank > 0) {
+        const int at = st.sp + (n_hit - 1 - rank);
+        if (at < QUAD_STACK_DEPTH) {
+            st.column[at * st.stride].node = child;
+            st.column[at * st.stride].tnear = t;
+        }
+        else atomicAdd(st.overflows, 1u); // never: the host bounds what a hierarchy needs (see TraversalStack::push)
+    }
+    st.sp = min(st.sp + n_hit - 1, QUAD_STACK_DEPTH);
+    return quad_sum(ok && rank == 0 ? child : 0);
+}
+
+// Leaf `leaf` for one ray: lane c tests triangle c (and c + 4, ... for leaves of more than four).  Returns whether a
+// triangle became the ray's closest hit; t_best and prim_best are updated in all four lanes.  Ties between the
+// triangles of a leaf go to the first, as in the one-lane walk.
+PTK_DEV bool visit_leaf_quad(const DevScene& sc, int32_t leaf, int64_t first_tri, int c, const V3& org, const RayPrep& rp, double& t_best,
+                             int& prim_best) {
+    const uint32_t code = static_cast<uint32_t>(~leaf);
+    const int64_t first = first_tri + (code >> 3);
+    const int count = static_cast<int>(code & 7u) + 1;
+    bool found = false;
+    for (int base = 0; base < count; base += 4) { // quad-uniform
+        const int k = base + c;
+        double d = INF;
+        bool valid = false;
+        if (k < count) {
+            valid = triangle_hit(sc.tri_hot[first + k], org, rp, t_best, d) && d > EPSILON && d < t_best;
+            if (!valid) d = INF;
+        }
+        const double d1 = quad_perm_d<QUAD_ROTATE_1>(d), d2 = quad_perm_d<QUAD_ROTATE_2>(d), d3 = quad_perm_d<QUAD_ROTATE_3>(d);
+        const bool beaten = (d1 < d || (d1 == d && c + 1 >= 4)) || (d2 < d || (d2 == d && c + 2 >= 4)) || (d3 < d || (d3 == d && c + 3 >= 4));
+        const bool winner = valid && !beaten;
+        if (quad_sum(winner ? 1 : 0) != 0) {
+            const int lo = quad_sum(winner ? __double2loint(d) : 0), hi = quad_sum(winner ? __double2hiint(d) : 0);
+            t_best = __hiloint2double(hi, lo);
+            prim_best = quad_sum(winner ? static_cast<int>(first + k) : 0);
+            found = true;
+        }
+    }
+    return found;
+}
+
 // largest absolute coordinate of a mesh's bounds (DevShape::f[0..5])
 PTK_DEV float mesh_bound_abs(const DevShape& o) {
     double m = 0;

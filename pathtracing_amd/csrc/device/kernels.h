@@ -21,6 +21,7 @@ uint32_t chunk_capacity(uint32_t records);
 struct LaunchContext {
     hipStream_t stream;
     uint32_t compute_units; // of the device the stream belongs to: sizes the grids of the persistent kernels
+    bool quad_traverse;     // true: the hierarchy walks of queued rays use four lanes per ray (k_traverse_quad), false: one
     bool specialised;       // false: every scene runs the general kernels (all features compiled in, tables read from
                             // memory) instead of the ones specialised on its contents; the results are the same
 };

@@ -161,6 +161,8 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_WAVES) void 
         const unsigned long long idle = __ballot(!has_ray);
         const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle));
         if (!exhausted && n_idle >= REFILL_LANES) {
+            // (one atomic per fetch: reserving 64 to 256 rays per wave and atomic instead changed nothing here, 67 to 71 ms
+            // against 65 per two steps of the 1M-triangle workload, unlike in k_traverse_quad below)
             uint32_t base = 0;
             if (lanes_below(idle) == 0 && !has_ray) base = atomicAdd(queues.counters + 2, n_idle); // the first idle lane
             base = __shfl(base, __ffsll(static_cast<long long>(idle)) - 1);
@@ -224,6 +226,129 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_WAVES) void 
     }
     stat[1] = st.nodes_visited;
     stat[2] = st.triangles_tested;
+    add_block_statistics(statistics, wave_sums, stat);
+}
+
+// The same with four lanes per ray (geometry.h, "four lanes per ray"): a wave holds 16 rays; at an inner node each of a
+// ray's lanes tests one child box, at a leaf one triangle.  Per node a ray then costs two 16-byte loads per lane that the
+// four lanes aim at one 128-byte line, instead of seven loads of one lane.  A quad whose ray is finished takes a new one
+// from the queue once REFILL_QUADS of the wave's 16 are idle.
+// Measured on one MI355X, 1,048,576-triangle workload, per two steps: 84 ms against the 65 ms of k_traverse (so that one
+// stays the default; ptk_set_option "traverse_lanes" selects).  The rays of a wave are in different phases of their
+// walks here as there (15.4 of 64 lanes, i.e. four of sixteen quads, are active per vector instruction, 11.6 lanes in
+// k_traverse), and a wave of 16 rays has a quarter of the loads in flight; 4 waves per SIMD: 96 ms, 6: 85 ms, 7 and 8
+// (with registers spilled): 112 and 153 ms; refill at 2, 4 or 8 idle quads: no difference.
+#ifndef PTK_REFILL_QUADS
+#define PTK_REFILL_QUADS 4
+#endif
+#ifndef PTK_QUAD_RAY_CHUNK
+#define PTK_QUAD_RAY_CHUNK 32
+#endif
+constexpr int REFILL_QUADS = PTK_REFILL_QUADS;
+// A wave reserves this many rays of the queue at a time and hands them to its quads as they fall idle: one atomic on
+// the queue's counter per chunk (that one address serves about a hundred atomics per microsecond, and a wave of 16
+// rays would otherwise ask several times as often as one of 64).
+constexpr uint32_t QUAD_RAY_CHUNK = PTK_QUAD_RAY_CHUNK;
+constexpr int QUAD_RAYS_PER_BLOCK = BLOCK / 4;
+
+__global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_QUAD_WAVES) void k_traverse_quad(DevScene sc, DeferQueues queues,
+                                                                                                     unsigned long long* statistics) {
+    __shared__ StackEntry lds_stack[QUAD_STACK_DEPTH * QUAD_RAYS_PER_BLOCK];
+    __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
+    __shared__ DevMeshRef lds_meshes[TRAVERSE_QUAD_LDS_MESHES];
+    const uint32_t n = queues.counters[0];
+    const bool meshes_in_lds = sc.n_meshes <= TRAVERSE_QUAD_LDS_MESHES;
+    if (meshes_in_lds) {
+        for (int i = threadIdx.x; i < sc.n_meshes; i += BLOCK) lds_meshes[i] = sc.meshes[i];
+        __syncthreads();
+    }
+    const int c = threadIdx.x & 3; // this lane's child / triangle
+    QuadStack st;
+    st.column = (LdsStackEntry*) lds_stack + (threadIdx.x >> 2);
+    st.stride = QUAD_RAYS_PER_BLOCK;
+    st.sp = 0;
+    st.overflows = sc.stack_overflows;
+    uint32_t stat[N_STATISTICS] = {}; // [0] rays, [1] nodes visited, [2] triangles tested (counted by lane 0 of each quad)
+    bool exhausted = false;           // wave-uniform: the queue has been handed out completely
+    uint32_t reserved_next = 0, reserved_end = 0; // wave-uniform: the rays this wave has reserved and not yet handed out
+    bool has_ray = false;             // everything from here on is the same in the four lanes of a quad
+    V3 org = v3(0.0);
+    RayPrep rp{};
+    SlabRay1 slab{};
+    RayResult best{INF, -1, 0};
+    uint32_t slot = 0;
+    int mesh = 0, object = 0;
+    int64_t first_tri = 0;
+    bool any_hit = false;
+    int32_t node = BVH_EMPTY;
+    for (;;) {
+        const unsigned long long idle = __ballot(!has_ray);
+        const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle)) / 4u; // quads
+        if (!exhausted && n_idle >= REFILL_QUADS) {
+            if (reserved_next >= reserved_end) { // reserve the next chunk of the queue
+                uint32_t base = 0;
+                if ((threadIdx.x & 63) == 0) base = atomicAdd(queues.counters + 2, QUAD_RAY_CHUNK);
+                base = __builtin_amdgcn_readfirstlane(base);
+                reserved_next = min(base, n);
+                reserved_end = min(base + QUAD_RAY_CHUNK, n);
+                exhausted = base >= n;
+            }
+            if (!has_ray) {
+                const uint32_t i = reserved_next + lanes_below(idle) / 4u;
+                if (i < reserved_end) {
+                    const RayRequest q = queues.rays[i]; // the four lanes read the same 64 bytes
+                    org = v3(q.ox, q.oy, q.oz);
+                    const V3 dir = v3(q.dx, q.dy, q.dz);
+                    rp = prepare_ray(dir);
+                    slab = slab_ray1(org, dir, sc.mesh_bound_abs);
+                    best = RayResult{q.limit, static_cast<int32_t>(q.object), 0};
+                    slot = q.slot;
+                    mesh = -1;
+                    node = BVH_EMPTY;
+                    has_ray = true;
+                    if (c == 0) stat[0]++;
+                }
+            }
+            reserved_next = min(reserved_next + n_idle, reserved_end);
+        }
+        if (__ballot(has_ray) == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        if (has_ray && node == BVH_EMPTY) { // between meshes: on to the ray's next mesh, or the ray is finished
+            mesh++;
+            if (mesh < sc.n_meshes) {
+                const DevMeshRef m = meshes_in_lds ? lds_meshes[mesh] : sc.meshes[mesh];
+                object = m.object;
+                node = m.bvh_root;
+                first_tri = m.first_tri;
+                any_hit = (slot & 1u) == 0 && m.opaque != 0; // see k_traverse
+                st.sp = 0;
+            }
+            else {
+                if (c == 0) queues.results[slot] = best;
+                has_ray = false;
+            }
+        }
+        while (node >= 0) {
+            if (c == 0) stat[1]++;
+            node = visit_inner_quad(sc.nodes_quad, node, c, slab, best.t, st);
+        }
+        while (node < 0 && node != BVH_EMPTY) {
+            if (c == 0) stat[2] += (static_cast<uint32_t>(~node) & 7u) + 1u;
+            int prim = -1;
+            const bool found = visit_leaf_quad(sc, node, first_tri, c, org, rp, best.t, prim);
+            node = pop_closer_quad(st, best.t);
+            if (found) {
+                best.obj = object;
+                best.prim = prim;
+                if (any_hit) {
+                    mesh = sc.n_meshes;
+                    node = BVH_EMPTY;
+                }
+            }
+        }
+    }
     add_block_statistics(statistics, wave_sums, stat);
 }
 
@@ -497,6 +622,13 @@ void launch_tail(const LaunchContext& lc, uint32_t bound, const DevScene& sc, co
 
 void launch_traverse(const LaunchContext& lc, uint32_t bound, const DevScene& sc, const DeferQueues& queues, unsigned long long* statistics) {
     const hipStream_t s = lc.stream;
+    if (lc.quad_traverse) {
+        // one device fill of waves that hold 16 rays each
+        const uint32_t resident = lc.compute_units * PTK_TRAVERSE_QUAD_WAVES;
+        const dim3 grid(min((2 * bound + QUAD_RAYS_PER_BLOCK - 1) / QUAD_RAYS_PER_BLOCK + 1, resident));
+        hipLaunchKernelGGL(k_traverse_quad, grid, dim3(BLOCK), 0, s, sc, queues, statistics);
+        return;
+    }
     // enough blocks to fill the device once (PTK_TRAVERSE_WAVES waves per SIMD, four SIMDs per CU, four waves per block)
     const uint32_t resident = lc.compute_units * PTK_TRAVERSE_WAVES;
     const dim3 grid(min((2 * bound + BLOCK - 1) / BLOCK + 1, resident));

@@ -46,6 +46,9 @@ constexpr int BLOCK = 256;
 #ifndef PTK_TRAVERSE_WAVES
 #define PTK_TRAVERSE_WAVES 5
 #endif
+#ifndef PTK_TRAVERSE_QUAD_WAVES
+#define PTK_TRAVERSE_QUAD_WAVES 5
+#endif
 #define PTK_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 static_assert(BLOCK == BIN_BLOCK, "k_extend and the bin kernels share their block geometry");
 

@@ -93,6 +93,7 @@ struct DevMeshRef { // 16 bytes
     int32_t opaque;    // no connection to a light passes through this mesh (DevShape::f[6])
 };
 constexpr int TRAVERSE_LDS_MESHES = 256; // entries of the list of meshes k_traverse keeps in LDS
+constexpr int TRAVERSE_QUAD_LDS_MESHES = 128; // the same for k_traverse_quad
 
 struct TriHot { // vertices, fp64
     double p1[3], p2[3], p3[3];
@@ -114,6 +115,22 @@ struct BvhNode4 { // 128 bytes
     int32_t _pad[4];
 };
 constexpr int32_t BVH_EMPTY = INT32_MIN;
+// The same node for k_traverse, which walks a hierarchy with four lanes per ray, one lane per child: child c's box
+// and reference are 32 consecutive bytes (two 16-byte loads per lane; the four lanes of a ray read the four quarters
+// of one 128-byte line with each of them).
+struct BvhChildBox { // 32 bytes
+    float lo[3], hi[3];
+    int32_t child; // as BvhNode4::child
+    int32_t _pad;
+};
+struct BvhNodeQuad { // 128 bytes
+    BvhChildBox c[4];
+};
+// entries of the per-ray traversal stack of k_traverse (LDS); the builder is asked for trees that need fewer
+#ifndef PTK_QUAD_STACK
+#define PTK_QUAD_STACK 56
+#endif
+constexpr int QUAD_STACK_DEPTH = PTK_QUAD_STACK;
 // traversal stack: entries kept in LDS per lane, and in a private spill array beyond that
 #ifndef PTK_LDS_STACK
 #define PTK_LDS_STACK 12
@@ -150,6 +167,7 @@ struct DevScene {
     const TriHot* tri_hot;
     const TriCold* tri_cold;
     const BvhNode4* nodes;
+    const BvhNodeQuad* nodes_quad;       // the same nodes, same indices, in the layout of k_traverse
     const double* light_cumulative_area; // per mesh light: cumulative areas in OBJ face order
     const int32_t* light_tri_index;      // per mesh light: root-sorted position -> triangle (leaf order)
     const DevMeshRef* meshes;            // [n_meshes]

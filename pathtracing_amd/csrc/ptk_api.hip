@@ -57,6 +57,7 @@ std::atomic<bool> g_profiling{false};
 constexpr uint32_t TAIL_RECORDS_LIMIT = 1u << 24; // upper limit of the tail_records option (no batch is larger)
 std::atomic<uint32_t> g_tail_records{TAIL_RECORDS};
 std::atomic<bool> g_specialised{true};
+std::atomic<bool> g_quad_traverse{false};
 
 int fail(int code, const std::string& message) {
     g_error = message;
@@ -90,7 +91,7 @@ int use(const DeviceContext* ctx) {
     return PTK_OK;
 }
 LaunchContext launch_context(const DeviceContext* ctx) {
-    return LaunchContext{ctx->stream, ctx->compute_units, g_specialised.load()};
+    return LaunchContext{ctx->stream, ctx->compute_units, g_quad_traverse.load(), g_specialised.load()};
 }
 
 // Exceptions never cross the C boundary: the bodies of the entry points that allocate or parse run inside these.
@@ -558,6 +559,11 @@ int ptk_set_option(const char* name, int64_t value) {
         g_tail_records = static_cast<uint32_t>(value);
         return PTK_OK;
     }
+    if (name && std::strcmp(name, "traverse_lanes") == 0) {
+        if (value != 1 && value != 4) return fail(PTK_ERR_INVALID, "ptk_set_option: traverse_lanes must be 1 or 4");
+        g_quad_traverse = value == 4;
+        return PTK_OK;
+    }
     if (name && std::strcmp(name, "specialised_kernels") == 0) {
         if (value != 0 && value != 1) return fail(PTK_ERR_INVALID, "ptk_set_option: specialised_kernels must be 0 or 1");
         g_specialised = value != 0;
@@ -766,9 +772,9 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
                 // bvh_leaf_size tunes the reference's tree for its cost balance; here an exact fp64 triangle test costs
                 // about as much as a 4-wide node, so leaves hold at most two triangles (measured: +6 % over four)
                 BuiltBvh bvh = build_bvh4(verts, n, std::min(d->settings.bvh_leaf_size, 2), d->settings.bvh_n_axis_splits, build_threads,
-                                          LDS_STACK_DEPTH + SPILL_STACK_DEPTH);
+                                          std::min(LDS_STACK_DEPTH + SPILL_STACK_DEPTH, QUAD_STACK_DEPTH - 1));
                 // backstop: the builder bounds the stack its tree needs (build_bvh4), so this cannot fail
-                if (bvh.max_stack > LDS_STACK_DEPTH + SPILL_STACK_DEPTH)
+                if (bvh.max_stack > std::min(LDS_STACK_DEPTH + SPILL_STACK_DEPTH, QUAD_STACK_DEPTH - 1))
                     return fail(PTK_ERR_MEMORY, "ptk_scene_create: mesh hierarchy needs a deeper traversal stack than the kernels have");
                 std::vector<int32_t> leaf_position(static_cast<size_t>(n)); // face -> position in leaf order
                 for (int64_t k = 0; k < n; k++) leaf_position[bvh.order[static_cast<size_t>(k)]] = static_cast<int32_t>(k);
@@ -964,6 +970,22 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     HIP_TRY(buf.upload(&dev.tri_hot, tri_hot));
     HIP_TRY(buf.upload(&dev.tri_cold, tri_cold));
     HIP_TRY(buf.upload(&dev.nodes, nodes));
+    {
+        std::vector<BvhNodeQuad> quads(nodes.size()); // the same nodes in the layout of k_traverse_quad
+        for (size_t i = 0; i < nodes.size(); i++)
+            for (int c = 0; c < 4; c++) {
+                BvhChildBox& box = quads[i].c[c];
+                box.lo[0] = nodes[i].lo_x[c];
+                box.lo[1] = nodes[i].lo_y[c];
+                box.lo[2] = nodes[i].lo_z[c];
+                box.hi[0] = nodes[i].hi_x[c];
+                box.hi[1] = nodes[i].hi_y[c];
+                box.hi[2] = nodes[i].hi_z[c];
+                box.child = nodes[i].child[c];
+                box._pad = 0;
+            }
+        HIP_TRY(buf.upload(&dev.nodes_quad, quads));
+    }
     std::vector<DevMeshRef> mesh_refs; // what k_traverse needs to start the walk of each mesh
     for (size_t i = 0; i < shapes.size(); i++)
         if (shapes[i].type == PTK_OBJ_MESH && shapes[i].bvh_root >= 0)

@@ -14,6 +14,11 @@ import pathtracing_amd as pt  # noqa: E402
 from pathtracing_amd import scenes  # noqa: E402
 
 
+def trimmed_mean_difference(got, want):
+    keep = np.argsort(((got - want) ** 2).ravel())[:-31]
+    return (got.ravel()[keep].mean() - want.ravel()[keep].mean()) / want.ravel()[keep].mean()
+
+
 def main():
     spp = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     pt.init(0)
@@ -32,7 +37,8 @@ def main():
                   "rRMSE %.4f" % (np.sqrt(np.mean((got[..., c] - want[..., c]) ** 2)) / mean),
                   "trimmed rRMSE %.4f" % (np.sqrt(np.mean(np.sort(((got[..., c] - want[..., c]) ** 2).ravel())[:-31])) / mean),
                   "rMAE %.4f" % (np.mean(np.abs(got[..., c] - want[..., c])) / mean),
-                  "mean diff %.5f" % ((got[..., c].mean() - mean) / mean))
+                  "mean diff %.5f" % ((got[..., c].mean() - mean) / mean),
+                  "mean diff without the 2%% of pixels that differ most %.5f" % trimmed_mean_difference(got[..., c], want[..., c]))
 
 
 if __name__ == "__main__":
