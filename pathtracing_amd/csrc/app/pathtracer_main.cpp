@@ -1,4 +1,5 @@
-// pathtracer <scene_directory> [--device N] [--seed S] [--flush-every K] [--resume 1]
+// pathtracer <scene_directory> [--device N | --gpus N | --devices a,b,...] [--partition tiles|samples] [--seed S]
+//            [--flush-every K] [--resume 1]
 //
 // Command-line driver with the reference's contract (app/pathtracer.cpp:300-380): reads
 // <scene_directory>/settings.json and scene.json, renders samples_per_pixel samples in iterations of
@@ -10,12 +11,21 @@
 // the driver also writes ./temp/raw_progress.dat (per-pixel sample counts, the seed and the number of samples
 // done); `--resume 1` picks a render up from those files and continues to samples_per_pixel, drawing the sample
 // indices that are still missing (the reference cannot resume: its random streams are not addressable).
+//
+// Several GPUs (--gpus N: devices 0 .. N-1; --devices: any list): the scene is replicated, one host thread per GPU
+// drives that GPU's own stream, and every iteration is dealt out either as interleaved bands of eight image rows
+// (--partition tiles, the default: a GPU renders all samples of its own pixels) or as slices of the iteration's sample
+// indices (--partition samples: every GPU renders every pixel).  This replaces the reference's pool of threads pulling
+// pixel ranges from a job vector (app/pathtracer.cpp:337-365).  At every flush the per-GPU films are copied to the host
+// and merged, pixel by pixel, as the sample-count-weighted mean, into the mapped files.  The image does not depend on the
+// number of GPUs or on the partition (tiles: bit for bit; samples: up to the rounding of the merged mean).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ptk.h"
@@ -62,21 +72,81 @@ int die(const std::string& message) {
     std::cerr << "pathtracer: " << message << std::endl;
     return EXIT_FAILURE;
 }
+
+struct Worker { // one GPU: its copy of the scene and its film
+    int device = 0;
+    PtkScene* scene = nullptr;
+    PtkFilm* film = nullptr;
+    int status = PTK_OK;
+    std::string error;
+};
+
+// This worker's share of an iteration of `n_samples` samples starting at sample index `first_sample`.
+void render_share(Worker& w, size_t rank, size_t world, bool tiles, int32_t width, int32_t height, int32_t first_sample, int32_t n_samples,
+                  uint64_t seed) {
+    PtkRenderJob job{};
+    job.seed = seed;
+    if (tiles && world > 1) { // bands of 8 rows, band b belongs to worker b % world
+        const int64_t band_rows = 8, band_pixels = band_rows * width;
+        const int64_t n_bands = (height + band_rows - 1) / band_rows;
+        int64_t pixels = 0;
+        for (int64_t band = static_cast<int64_t>(rank); band < n_bands; band += static_cast<int64_t>(world))
+            pixels += std::min<int64_t>(band_rows, height - band * band_rows) * width;
+        if (pixels == 0) return;
+        job.start_idx = static_cast<int64_t>(rank) * band_pixels;
+        job.number_of_pixels = pixels;
+        job.number_of_samples = n_samples;
+        job.sample_offset = first_sample;
+        w.status = ptk_render_bands(w.scene, w.film, &job, band_pixels, static_cast<int64_t>(world) * band_pixels);
+    }
+    else { // a contiguous slice of the iteration's sample indices
+        const int32_t base = n_samples / static_cast<int32_t>(world), extra = n_samples % static_cast<int32_t>(world);
+        const int32_t r = static_cast<int32_t>(rank);
+        const int32_t count = base + (r < extra ? 1 : 0), first = r * base + std::min(r, extra);
+        if (count == 0) return;
+        job.start_idx = 0;
+        job.number_of_pixels = static_cast<int64_t>(width) * height;
+        job.number_of_samples = count;
+        job.sample_offset = first_sample + first;
+        w.status = ptk_render(w.scene, w.film, &job);
+    }
+    if (w.status != PTK_OK) w.error = ptk_last_error(); // the message is thread local
+}
 } // namespace
 
 int main(int argc, char* argv[]) {
     if (argc < 2 || argv[1][0] == '-') {
         std::cerr << "Invalid arguments provided.\n"
-                     "Usage: pathtracer <scene_directory> [--device N] [--seed S] [--flush-every K] [--resume 1]\n\n"
+                     "Usage: pathtracer <scene_directory> [--device N | --gpus N | --devices a,b,...] [--partition tiles|samples]\n"
+                     "                  [--seed S] [--flush-every K] [--resume 1]\n\n"
                      "positional arguments:\n"
                      "   scene_directory                  path to the scene directory (relative to main project directory)\n";
         return EXIT_FAILURE;
     }
     const std::string dir = argv[1];
-    int device = 0, flush_every = 0, resume = 0;
+    int flush_every = 0, resume = 0;
     unsigned long long seed = 0;
+    std::vector<int> devices;
+    bool tiles = true;
     for (int i = 2; i + 1 < argc; i += 2) {
-        if (!std::strcmp(argv[i], "--device")) device = std::atoi(argv[i + 1]);
+        if (!std::strcmp(argv[i], "--device")) devices.assign(1, std::atoi(argv[i + 1]));
+        else if (!std::strcmp(argv[i], "--gpus")) {
+            devices.clear();
+            for (int k = 0; k < std::atoi(argv[i + 1]); k++) devices.push_back(k);
+        }
+        else if (!std::strcmp(argv[i], "--devices")) {
+            devices.clear();
+            for (const char* p = argv[i + 1]; *p;) {
+                char* end = nullptr;
+                devices.push_back(static_cast<int>(std::strtol(p, &end, 10)));
+                if (end == p) return die("--devices: expected a comma-separated list of device indices");
+                p = *end == ',' ? end + 1 : end;
+            }
+        }
+        else if (!std::strcmp(argv[i], "--partition")) {
+            if (std::strcmp(argv[i + 1], "tiles") && std::strcmp(argv[i + 1], "samples")) return die("--partition: tiles or samples");
+            tiles = !std::strcmp(argv[i + 1], "tiles");
+        }
         else if (!std::strcmp(argv[i], "--seed")) seed = std::strtoull(argv[i + 1], nullptr, 10);
         else if (!std::strcmp(argv[i], "--flush-every")) flush_every = std::atoi(argv[i + 1]);
         else if (!std::strcmp(argv[i], "--resume")) resume = std::atoi(argv[i + 1]);
@@ -89,9 +159,14 @@ int main(int argc, char* argv[]) {
     PtkLoadedScene* loaded = nullptr;
     if (ptk_host_load_scene((dir + "/scene.json").c_str(), &settings, dir.c_str(), &loaded) != PTK_OK)
         return die(ptk_host_last_error());
-    if (ptk_init(device) != PTK_OK) return die(ptk_last_error());
-    PtkScene* scene = nullptr;
-    if (ptk_scene_create(ptk_host_scene_desc(loaded), 0, &scene) != PTK_OK) return die(ptk_last_error());
+    if (devices.empty()) devices.push_back(0);
+    std::vector<Worker> workers(devices.size());
+    for (size_t k = 0; k < workers.size(); k++) { // the scene is replicated: every GPU builds its own copy
+        workers[k].device = devices[k];
+        if (ptk_init(devices[k]) != PTK_OK) return die(ptk_last_error());
+        if (ptk_scene_create(ptk_host_scene_desc(loaded), 0, &workers[k].scene) != PTK_OK) return die(ptk_last_error());
+        if (ptk_film_create(settings.width, settings.height, &workers[k].film) != PTK_OK) return die(ptk_last_error());
+    }
     ptk_host_free_scene(loaded);
     auto end_build = std::chrono::steady_clock::now();
     std::clog << "Time taken to build scene: " << std::chrono::duration_cast<std::chrono::seconds>(end_build - begin_build).count()
@@ -118,9 +193,17 @@ int main(int argc, char* argv[]) {
     double* normal = ptk_host_map_buffer("./temp/raw_normal.dat", file_size, resume ? 0 : 1, &normal_fd);
     if (!image || !position || !normal) return die(ptk_host_last_error());
 
-    PtkFilm* film = nullptr;
-    if (ptk_film_create(settings.width, settings.height, &film) != PTK_OK) return die(ptk_last_error());
-    if (resume && ptk_film_upload(film, image, position, normal, counters.data()) != PTK_OK) return die(ptk_last_error());
+    // a resumed render continues in the first GPU's film; the others start empty and the merge adds them up
+    if (resume && ptk_film_upload(workers[0].film, image, position, normal, counters.data()) != PTK_OK) return die(ptk_last_error());
+    // host copies of the other GPUs' films for the merge at every flush
+    std::vector<double> part_image, part_position, part_normal;
+    std::vector<uint64_t> part_counters;
+    if (workers.size() > 1) {
+        part_image.resize(pixel_count * 3);
+        part_position.resize(pixel_count * 3);
+        part_normal.resize(pixel_count * 3);
+        part_counters.resize(pixel_count);
+    }
 
     auto begin = std::chrono::steady_clock::now();
     auto last_flush = begin;
@@ -129,20 +212,40 @@ int main(int argc, char* argv[]) {
     const int first_sample = progress.samples_done;
     const int iterations = spp > first_sample ? (spp - first_sample - 1) / spi + 1 : 0;
     for (int j = 0; j < iterations; j++) {
-        PtkRenderJob job{};
-        job.start_idx = 0;
-        job.number_of_pixels = static_cast<int64_t>(pixel_count);
-        job.number_of_samples = std::min(spi, spp - progress.samples_done);
-        job.sample_offset = progress.samples_done;
-        job.seed = seed;
-        if (ptk_render(scene, film, &job) != PTK_OK) return die(ptk_last_error());
-        progress.samples_done += job.number_of_samples;
+        const int32_t n_samples = std::min(spi, spp - progress.samples_done);
+        if (workers.size() == 1) render_share(workers[0], 0, 1, tiles, settings.width, settings.height, progress.samples_done, n_samples, seed);
+        else { // one host thread per GPU
+            std::vector<std::thread> threads;
+            for (size_t k = 0; k < workers.size(); k++)
+                threads.emplace_back(render_share, std::ref(workers[k]), k, workers.size(), tiles, settings.width, settings.height,
+                                     progress.samples_done, n_samples, seed);
+            for (std::thread& t : threads) t.join();
+        }
+        for (const Worker& w : workers)
+            if (w.status != PTK_OK) return die(w.error);
+        progress.samples_done += n_samples;
         auto now = std::chrono::steady_clock::now();
         bool flush = j + 1 == iterations;
         if (flush_every > 0) flush |= (j + 1) % flush_every == 0;
         else flush |= std::chrono::duration_cast<std::chrono::milliseconds>(now - last_flush).count() >= 1000;
         if (flush) {
-            if (ptk_film_download(film, image, position, normal, counters.data()) != PTK_OK) return die(ptk_last_error());
+            if (ptk_film_download(workers[0].film, image, position, normal, counters.data()) != PTK_OK) return die(ptk_last_error());
+            for (size_t k = 1; k < workers.size(); k++) { // merge: sample-count-weighted mean per pixel
+                if (ptk_film_download(workers[k].film, part_image.data(), part_position.data(), part_normal.data(), part_counters.data()) != PTK_OK)
+                    return die(ptk_last_error());
+                for (size_t p = 0; p < pixel_count; p++) {
+                    const uint64_t add = part_counters[p];
+                    if (add == 0) continue;
+                    const double n_prev = static_cast<double>(counters[p]), n_add = static_cast<double>(add);
+                    for (size_t c = 3 * p; c < 3 * p + 3; c++) {
+                        // a pixel only this GPU has rendered keeps its bits; otherwise increment_average's arithmetic
+                        image[c] = n_prev == 0 ? part_image[c] : (image[c] * n_prev + part_image[c] * n_add) / (n_prev + n_add);
+                        position[c] = n_prev == 0 ? part_position[c] : (position[c] * n_prev + part_position[c] * n_add) / (n_prev + n_add);
+                        normal[c] = n_prev == 0 ? part_normal[c] : (normal[c] * n_prev + part_normal[c] * n_add) / (n_prev + n_add);
+                    }
+                    counters[p] += add;
+                }
+            }
             if (!write_progress(progress, counters)) return die(std::string("cannot write ") + PROGRESS_FILE);
             last_flush = std::chrono::steady_clock::now();
             print_progress(static_cast<int>(100.0 * (j + 1) / iterations));
@@ -154,15 +257,22 @@ int main(int argc, char* argv[]) {
     const double seconds = std::chrono::duration_cast<std::chrono::milliseconds>(end - begin).count() / 1e3;
     std::clog << "Program complete. Time taken: " << std::chrono::duration_cast<std::chrono::seconds>(end - begin).count() << "[s]"
               << std::endl;
-    PtkStats st;
-    if (ptk_get_stats(scene, &st) == PTK_OK && seconds > 0)
-        std::clog << st.paths << " paths, " << (st.extension_rays + st.shadow_rays) << " rays, " << st.paths / seconds / 1e6
-                  << " Mpaths/s" << std::endl;
+    uint64_t paths = 0, rays = 0;
+    for (const Worker& w : workers) {
+        PtkStats st;
+        if (ptk_get_stats(w.scene, &st) != PTK_OK) continue;
+        paths += st.paths;
+        rays += st.extension_rays + st.shadow_rays;
+    }
+    if (seconds > 0)
+        std::clog << paths << " paths, " << rays << " rays, " << paths / seconds / 1e6 << " Mpaths/s on " << workers.size() << " GPU(s)" << std::endl;
 
     ptk_host_unmap_buffer(image, file_size, image_fd);
     ptk_host_unmap_buffer(position, file_size, position_fd);
     ptk_host_unmap_buffer(normal, file_size, normal_fd);
-    ptk_film_destroy(film);
-    ptk_scene_destroy(scene);
+    for (Worker& w : workers) {
+        ptk_film_destroy(w.film);
+        ptk_scene_destroy(w.scene);
+    }
     return 0;
 }

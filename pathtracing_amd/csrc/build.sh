@@ -22,7 +22,7 @@ wait
 hipcc --offload-arch=gfx950 -shared -fPIC $OBJECTS build/bvh_builder.o -o $OUT/libptk.so -lpthread
 mkdir -p $OUT/bin
 for app in pathtracer denoiser; do
-  g++ -std=c++17 -O2 -Wall -Wextra -I../../include app/${app}_main.cpp -o $OUT/bin/$app -L$OUT -lptk -lptkhost \
+  g++ -std=c++17 -O2 -Wall -Wextra -pthread -I../../include app/${app}_main.cpp -o $OUT/bin/$app -L$OUT -lptk -lptkhost \
       -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath-link,/opt/rocm/lib
 done
 echo "built $OUT/libptkhost.so $OUT/libptk.so $OUT/bin/pathtracer $OUT/bin/denoiser"

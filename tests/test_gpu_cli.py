@@ -73,3 +73,31 @@ def test_usage_and_error_messages(tmp_path):
     assert r.returncode != 0 and "Usage: pathtracer <scene_directory>" in r.stderr
     r = subprocess.run([os.path.join(BIN, "pathtracer"), str(tmp_path / "nowhere")], capture_output=True, text=True)
     assert r.returncode != 0 and "Could not open file" in r.stderr
+
+
+@pytest.mark.parametrize("partition", ["tiles", "samples"])
+def test_several_host_threads_and_films_give_the_single_gpu_image(tmp_path, partition):
+    """`--devices 0,0,0` runs the multi-GPU driver (one host thread, scene copy and film per entry, merge at every flush)
+    on the one GPU of the box: interleaved bands give the single-GPU files bit for bit, sample slices up to the rounding
+    of the merged mean."""
+    work = tmp_path / "work"
+    (work / "temp").mkdir(parents=True)
+    exe = os.path.join(BIN, "pathtracer")
+    d = scenes.mesh_box(str(work / "scene"), WIDTH=64, HEIGHT=44, samples_per_pixel=10, samples_per_iteration=4) and str(work / "scene")
+    shape = (44, 64, 3)
+
+    def run(*extra):
+        r = subprocess.run([exe, d, "--seed", "3", "--flush-every", "1", *extra], cwd=str(work), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        return [np.fromfile(str(work / "temp" / f"raw_{name}.dat")).reshape(shape) for name in ("pixel", "position", "normal")], r.stderr
+
+    single, _ = run()
+    multi, log = run("--devices", "0,0,0", "--partition", partition)
+    assert "on 3 GPU(s)" in log
+    for a, b in zip(single, multi):
+        if partition == "tiles":
+            assert np.array_equal(a, b)
+        else:
+            np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-14)
+    counts = np.frombuffer(np.fromfile(str(work / "temp" / "raw_progress.dat"), dtype=np.uint8)[32:].tobytes(), dtype=np.uint64)
+    assert (counts == 10).all()
