@@ -279,6 +279,12 @@ int ptk_render_bands(PtkScene* scene, PtkFilm* film, const PtkRenderJob* job, in
 int ptk_render_host(PtkScene* scene, const PtkRenderJob* job, double* image, double* position, double* normal,
                     uint64_t* counters);
 
+/* How the mesh hierarchies of a scene were built (no counterpart in the reference, which prints the whole scene set-up
+ * time, app/pathtracer.cpp:309-316): the time of the builds of all meshes together in milliseconds (device time of the
+ * build kernels for meshes built on the GPU, wall time of the multi-threaded host build otherwise), how many meshes went
+ * which way, and the number of 4-wide nodes.  Any pointer may be NULL. */
+int ptk_scene_build_info(PtkScene* scene, double* bvh_build_ms, int32_t* meshes_built_on_gpu, int32_t* meshes_built_on_host,
+                         int64_t* bvh_nodes);
 int ptk_get_stats(PtkScene* scene, PtkStats* stats);
 /* Name, as a profiler shows it, of the k_bounce instantiation this scene is traced with (the library compiles one per
  * combination of scene features).  No counterpart in the reference; for benchmark reports. */
@@ -290,7 +296,10 @@ int ptk_reset_stats(PtkScene* scene);
 int ptk_set_profiling(int enabled);
 /* Tuning knobs, by name, process-wide (no counterpart in the reference).  "tail_records": once at most this many paths of a
  * batch are left, one kernel launch follows each of them to its end instead of running three launches per bounce
- * (0 switches that off; default 1048576, upper limit 16777216; scenes with meshes switch at four times the value).  "traverse_lanes": 1 (default) walks the hierarchies of queued rays with one
+ * (0 switches that off; default 1048576, upper limit 16777216; scenes with meshes switch at four times the value).  "gpu_bvh_build": 1 builds the hierarchy of every mesh of 1024
+ * triangles or more on the GPU when the next scenes are created (a linear BVH over Morton-ordered triangles: built in
+ * milliseconds, costlier to walk than the host's surface-area tree); 0 (default) builds on the host.
+ * "traverse_lanes": 1 (default) walks the hierarchies of queued rays with one
  * lane per ray; 4 with four lanes per ray, one per child box or triangle (slower as measured).  "specialised_kernels": 1 (default) traces a scene with the
  * kernels compiled for what it contains (no triangles, no texture coordinates, tables small enough for on-chip
  * copies, ...); 0 makes every scene use the general kernels that scenes with many objects get.  Unknown names and

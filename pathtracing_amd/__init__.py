@@ -306,6 +306,12 @@ class DeviceScene:
         _check_dev(device_lib().ptk_get_stats(self._handle, C.byref(s)))
         return s
 
+    def build_info(self):
+        """{'bvh_build_ms', 'meshes_built_on_gpu', 'meshes_built_on_host', 'bvh_nodes'} of this scene's mesh hierarchies."""
+        ms, gpu, host, nodes = C.c_double(), C.c_int32(), C.c_int32(), C.c_int64()
+        _check_dev(device_lib().ptk_scene_build_info(self._handle, C.byref(ms), C.byref(gpu), C.byref(host), C.byref(nodes)))
+        return {"bvh_build_ms": ms.value, "meshes_built_on_gpu": gpu.value, "meshes_built_on_host": host.value, "bvh_nodes": nodes.value}
+
     def bounce_kernel(self):
         """Profiler name of the k_bounce instantiation this scene uses."""
         return device_lib().ptk_scene_bounce_kernel(self._handle).decode()

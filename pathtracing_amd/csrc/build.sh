@@ -13,7 +13,7 @@ HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../i
 mkdir -p build
 # The instantiations of the path-tracing kernel templates are spread over device/variants/*.hip so that they
 # compile side by side (PTK_JOBS at a time).
-SOURCES="device/kernels.hip device/denoise.hip ptk_api.hip $(ls device/variants/*.hip)"
+SOURCES="device/kernels.hip device/denoise.hip device/bvh_build.hip ptk_api.hip $(ls device/variants/*.hip)"
 OBJECTS=""
 for src in $SOURCES; do OBJECTS="$OBJECTS build/$(basename $src .hip).o"; done
 g++ -std=c++17 -O3 -fPIC -I../../include -I. -c host/bvh_builder.cpp -o build/bvh_builder.o &

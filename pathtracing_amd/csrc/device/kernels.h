@@ -69,6 +69,14 @@ void launch_primary(hipStream_t s, const DevScene& sc, const BatchParams& b, int
 void launch_selftest_staging(hipStream_t s, uint32_t blocks, const PathPool& in, const PathPool& out, const uint32_t* list, uint32_t n,
                              const double* noise, uint32_t noise_mask, double* sink);
 
+// bvh_build.hip: the hierarchy of `n` triangles (9 doubles each, host memory) built on the current device (linear BVH
+// over Morton-ordered triangles, collapsed to 4-wide nodes).  false: not built (fewer than 1024 triangles, a tree
+// that needs more than `stack_limit` stack entries, or a HIP error, left in *error) and the caller builds on the
+// host.  build_ms: device time of the build kernels.
+struct BuiltBvh;
+bool build_bvh4_gpu(const double* vertices, int64_t n, int max_leaf, int stack_limit, hipStream_t stream, BuiltBvh& result, double* build_ms,
+                    hipError_t* error);
+
 // denoise.hip
 void launch_atrous(hipStream_t s, int width, int height, const double* image_in, double* image_out, const double* position,
                    const double* normal, double sigma_rt, double sigma_x, double sigma_n, int hole_width);

@@ -58,6 +58,7 @@ constexpr uint32_t TAIL_RECORDS_LIMIT = 1u << 24; // upper limit of the tail_rec
 std::atomic<uint32_t> g_tail_records{TAIL_RECORDS};
 std::atomic<bool> g_specialised{true};
 std::atomic<bool> g_quad_traverse{false};
+std::atomic<bool> g_gpu_bvh_build{false};
 
 int fail(int code, const std::string& message) {
     g_error = message;
@@ -238,6 +239,9 @@ struct PtkScene {
     std::vector<int> classes; // queue classes present in the scene
     PtkFilm* host_film = nullptr; // scratch film for ptk_render_host
     PtkStats stats{};
+    double bvh_build_ms = 0;      // hierarchy builds of all meshes: device time (GPU build) or wall time (host build)
+    int32_t bvh_meshes_on_gpu = 0, bvh_meshes_on_host = 0;
+    int64_t bvh_nodes = 0;
     std::vector<hipEvent_t> events;
     PtkScene() = default;
     PtkScene(const PtkScene&) = delete;
@@ -559,6 +563,11 @@ int ptk_set_option(const char* name, int64_t value) {
         g_tail_records = static_cast<uint32_t>(value);
         return PTK_OK;
     }
+    if (name && std::strcmp(name, "gpu_bvh_build") == 0) {
+        if (value != 0 && value != 1) return fail(PTK_ERR_INVALID, "ptk_set_option: gpu_bvh_build must be 0 or 1");
+        g_gpu_bvh_build = value != 0;
+        return PTK_OK;
+    }
     if (name && std::strcmp(name, "traverse_lanes") == 0) {
         if (value != 1 && value != 4) return fail(PTK_ERR_INVALID, "ptk_set_option: traverse_lanes must be 1 or 4");
         g_quad_traverse = value == 4;
@@ -771,8 +780,22 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
                 const double* verts = d->tri_vertices + 9 * po.first_triangle;
                 // bvh_leaf_size tunes the reference's tree for its cost balance; here an exact fp64 triangle test costs
                 // about as much as a 4-wide node, so leaves hold at most two triangles (measured: +6 % over four)
-                BuiltBvh bvh = build_bvh4(verts, n, std::min(d->settings.bvh_leaf_size, 2), d->settings.bvh_n_axis_splits, build_threads,
-                                          std::min(LDS_STACK_DEPTH + SPILL_STACK_DEPTH, QUAD_STACK_DEPTH - 1));
+                const int stack_limit = std::min(LDS_STACK_DEPTH + SPILL_STACK_DEPTH, QUAD_STACK_DEPTH - 1);
+                const int max_leaf = std::min(d->settings.bvh_leaf_size, 2);
+                BuiltBvh bvh;
+                double build_ms = 0;
+                hipError_t build_error = hipSuccess;
+                if (g_gpu_bvh_build.load() && build_bvh4_gpu(verts, n, max_leaf, stack_limit, ctx->stream, bvh, &build_ms, &build_error))
+                    s->bvh_meshes_on_gpu++;
+                else {
+                    HIP_TRY(build_error);
+                    const auto t0 = std::chrono::steady_clock::now();
+                    bvh = build_bvh4(verts, n, max_leaf, d->settings.bvh_n_axis_splits, build_threads, stack_limit);
+                    build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                    s->bvh_meshes_on_host++;
+                }
+                s->bvh_build_ms += build_ms;
+                s->bvh_nodes += static_cast<int64_t>(bvh.nodes.size());
                 // backstop: the builder bounds the stack its tree needs (build_bvh4), so this cannot fail
                 if (bvh.max_stack > std::min(LDS_STACK_DEPTH + SPILL_STACK_DEPTH, QUAD_STACK_DEPTH - 1))
                     return fail(PTK_ERR_MEMORY, "ptk_scene_create: mesh hierarchy needs a deeper traversal stack than the kernels have");
@@ -1273,6 +1296,15 @@ const char* ptk_scene_bounce_kernel(PtkScene* s) {
     if (!s) return "";
     name = bounce_kernel_name(s->dev, g_specialised.load());
     return name.c_str();
+}
+
+int ptk_scene_build_info(PtkScene* s, double* bvh_build_ms, int32_t* meshes_built_on_gpu, int32_t* meshes_built_on_host, int64_t* bvh_nodes) {
+    if (!s) return fail(PTK_ERR_INVALID, "ptk_scene_build_info: null scene");
+    if (bvh_build_ms) *bvh_build_ms = s->bvh_build_ms;
+    if (meshes_built_on_gpu) *meshes_built_on_gpu = s->bvh_meshes_on_gpu;
+    if (meshes_built_on_host) *meshes_built_on_host = s->bvh_meshes_on_host;
+    if (bvh_nodes) *bvh_nodes = s->bvh_nodes;
+    return PTK_OK;
 }
 
 int ptk_get_stats(PtkScene* s, PtkStats* stats) {
