@@ -17,6 +17,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIMDS = 256 * 4  # MI355X
+sys.path.insert(0, ROOT)
+from bench import sources_hash  # noqa: E402
 
 
 def main():
@@ -41,7 +43,7 @@ def main():
         if not waves:
             continue
         wave_cycles = c.get("SQ_WAVE_CYCLES", 0)   # x4 cycles, summed over waves
-        entry = {"waves": waves}
+        entry = {"waves": waves, "launches": len([1 for key in seen[k] if key[0] == paths[0]])}
         if c.get("SQ_INSTS_VALU"):
             entry["valu_per_wave"] = c["SQ_INSTS_VALU"] / waves
         if c.get("SQ_INSTS_SALU"):
@@ -50,6 +52,12 @@ def main():
             # average resident waves per SIMD = wave-cycles / (cycles the kernel was resident x SIMDs)
             busy = c["SQ_BUSY_CYCLES"] / 4.0  # reported per shader engine quadrant in cycles; see the table note
             entry["valu_share_of_wave_time"] = c["SQ_ACTIVE_INST_VALU"] / wave_cycles
+            # over the kernel's own duration in this pass (timestamps in ns, 2.4 GHz): resident waves per SIMD, and the
+            # share of the SIMDs' issue slots spent on vector instructions
+            if dur[k] > 0:
+                simd_cycles = dur[k] * 2.4 * SIMDS
+                entry["waves_per_simd"] = 4.0 * wave_cycles / simd_cycles
+                entry["simd_valu_busy"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / simd_cycles
         if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
             entry["active_lanes_per_valu"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]
         if wave_cycles and c.get("SQ_WAIT_INST_ANY"):
@@ -64,6 +72,7 @@ def main():
     js = os.path.join(out_dir, "counters_latest.json")
     data = json.load(open(js)) if os.path.exists(js) else {}
     data[workload] = latest
+    data.setdefault("_sources", {})[workload] = sources_hash()  # the code these numbers were measured on (bench.py checks it)
     json.dump(data, open(js, "w"), indent=1, sort_keys=True)
     with open(os.path.join(out_dir, f"{rnd}_{workload}_counters.md"), "w") as f:
         f.write(f"# SQ counters per kernel, workload `{workload}` ({rnd})\n\n")

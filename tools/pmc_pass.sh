@@ -7,4 +7,4 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 out=$R/gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 200 rocprofv3 --pmc $counters -d "$out" -o pmc --output-format csv -- python3 "$R/bench.py" --no-cpu-baseline --steps 1 --warmup 1 "$@" > "$out/bench.log" 2>&1
+timeout -s KILL 200 rocprofv3 --pmc $counters -d "$out" -o pmc --output-format csv -- python3 "$R/bench.py" --no-cpu-baseline --only-headline --steps 1 --warmup 1 "$@" > "$out/bench.log" 2>&1

@@ -20,6 +20,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+sys.path.insert(0, ROOT)
+from bench import sources_hash  # noqa: E402
+
+
 def kernel_name(raw):
     name = re.sub(r"\(.*", "", raw).replace("void ", "")
     return name.strip()
@@ -65,6 +69,7 @@ def main():
         with open(latest) as f:
             data = json.load(f)
     data[workload] = traffic
+    data.setdefault("_sources", {})[workload] = sources_hash()  # the code these numbers were measured on (bench.py checks it)
     with open(latest, "w") as f:
         json.dump(data, f, indent=1, sort_keys=True)
     with open(os.path.join(out_dir, f"{rnd}_{workload}_traffic.md"), "w") as f:
