@@ -173,7 +173,8 @@ PTK_DEV SlabRay slab_ray(const V3& org, const V3& dir, float bound_abs) {
 // One inner node (already in registers: `n`): tests its four boxes, pushes the children that can hold something
 // closer than t_best except the nearest, and returns the nearest (or the next entry of the stack when no child
 // qualifies).
-PTK_DEV int32_t visit_inner(const BvhNode4& n, const SlabRay& r, double t_best, TraversalStack& st) {
+// visit_inner_children leaves the last step to the caller: `pop` is set when no child qualifies.
+PTK_DEV int32_t visit_inner_children(const BvhNode4& n, const SlabRay& r, double t_best, TraversalStack& st, bool& pop) {
     const float FAR = __builtin_inff();
     st.nodes_visited++;
     float tn[4];
@@ -209,7 +210,13 @@ PTK_DEV int32_t visit_inner(const BvhNode4& n, const SlabRay& r, double t_best, 
     if (tn[3] < FAR) st.push(ch[3], tn[3]);
     if (tn[2] < FAR) st.push(ch[2], tn[2]);
     if (tn[1] < FAR) st.push(ch[1], tn[1]);
-    return tn[0] < FAR ? ch[0] : pop_closer(st, t_best);
+    pop = !(tn[0] < FAR);
+    return ch[0];
+}
+PTK_DEV int32_t visit_inner(const BvhNode4& n, const SlabRay& r, double t_best, TraversalStack& st) {
+    bool pop;
+    const int32_t nearest = visit_inner_children(n, r, t_best, st, pop);
+    return pop ? pop_closer(st, t_best) : nearest;
 }
 
 // One leaf: the exact test of its triangles; returns whether one of them became the closest hit.

@@ -44,7 +44,7 @@ constexpr int BLOCK = 256;
 #define PTK_BOUNCE_UV_WAVES 2
 #endif
 #ifndef PTK_TRAVERSE_WAVES
-#define PTK_TRAVERSE_WAVES 5
+#define PTK_TRAVERSE_WAVES 4
 #endif
 #ifndef PTK_TRAVERSE_QUAD_WAVES
 #define PTK_TRAVERSE_QUAD_WAVES 5
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
                 if (!deferred) new_cls = finish_vertex<TRIS, UV, PASS>(sc, out, res, dst, v, alive, scatter_distance, hit_of(sc, rays[0]), hit_of(sc, rays[1]), st, stat);
                 PTK_STAMP(1)
             }
-            if (DEFER) { // queue the deferred vertices of this round and their rays: two atomics per block
+            if (DEFER) { // queue the deferred vertices of this round and their rays: one atomic per block
                 const uint32_t my_rays = deferred ? (rays[0].needs_mesh ? 1u : 0u) + (rays[1].needs_mesh ? 1u : 0u) : 0u;
                 const unsigned long long vertex_mask = __ballot(deferred);
                 uint32_t rays_before = my_rays; // inclusive scan over the wave
@@ -787,10 +787,14 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
                     queue_counts[wave][1] = static_cast<uint32_t>(__popcll(vertex_mask));
                 }
                 __syncthreads();
-                if (threadIdx.x < 2) {
-                    uint32_t total = 0;
-                    for (int w = 0; w < BLOCK / 64; w++) total += queue_counts[w][threadIdx.x];
-                    queue_base[threadIdx.x] = total ? atomicAdd(queues.counters + threadIdx.x, total) : 0u;
+                if (threadIdx.x == 0) {
+                    // both counters with one 64-bit atomic (rays in the low half, which never carries: a batch queues
+                    // fewer than 2^32 rays): their one address serves about a hundred atomics per microsecond
+                    unsigned long long total = 0;
+                    for (int w = 0; w < BLOCK / 64; w++) total += queue_counts[w][0] + (static_cast<unsigned long long>(queue_counts[w][1]) << 32);
+                    const unsigned long long before = total ? atomicAdd(reinterpret_cast<unsigned long long*>(queues.counters), total) : 0ull;
+                    queue_base[0] = static_cast<uint32_t>(before);
+                    queue_base[1] = static_cast<uint32_t>(before >> 32);
                 }
                 __syncthreads();
                 if (deferred) {
@@ -854,6 +858,9 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
         const unsigned long long idle = __ballot(cls < 0);
         const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle));
         if (!exhausted && n_idle >= TAIL_REFILL_LANES) {
+            // (one atomic per fetch: a wave that reserves a longer stretch of the list and hands it out to its lanes
+            // over several fetches was slower here, 1371 against 1394 Mpaths/s on the Cornell scene: the list is short
+            // and its end is then held by few waves)
             uint32_t base = 0;
             if (cls < 0 && lanes_below(idle) == 0) base = atomicAdd(&info->cursor, n_idle); // the first idle lane
             base = __shfl(base, __ffsll(static_cast<long long>(idle)) - 1);

@@ -458,6 +458,10 @@ int trace_batch(PtkScene* s, const BatchParams& b) {
 #endif
     if (s->dev.has_meshes) { // k_traverse: ray request in, result out, 128-byte nodes, 72-byte triangle vertices
         const unsigned long long* t = s->h_rays + N_STATISTICS;
+#ifdef PTK_TRAVERSE_PROBE
+        std::fprintf(stderr, "traverse probe: rays %llu, nodes %llu, triangles %llu, passes of a wave %llu, lanes with a ray in them %llu\n",
+                     t[0], t[1], t[2], t[3], t[7]);
+#endif
         const uint64_t tb = TRAVERSE_BYTES_PER_RAY * t[0] + sizeof(BvhNode4) * t[1] + sizeof(TriHot) * t[2];
         st.traversed_rays += t[0];
         st.nodes_visited += t[1];
@@ -990,6 +994,7 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     std::vector<DevObject> light_objects;
     for (int32_t i : lights) light_objects.push_back(objects[static_cast<size_t>(i)]);
     HIP_TRY(buf.upload(&dev.light_objects, light_objects));
+    if (!tri_hot.empty()) tri_hot.push_back(TriHot{}); // k_traverse fetches 80 bytes where a triangle begins: eight past the last one
     HIP_TRY(buf.upload(&dev.tri_hot, tri_hot));
     HIP_TRY(buf.upload(&dev.tri_cold, tri_cold));
     HIP_TRY(buf.upload(&dev.nodes, nodes));
