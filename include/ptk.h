@@ -294,16 +294,24 @@ int ptk_reset_stats(PtkScene* scene);
  * when enabled, HIP events bracket every kernel family on the library's stream and the
  * *_ms fields of PtkStats accumulate device time.  Also enabled by PTK_PROFILE=1. */
 int ptk_set_profiling(int enabled);
-/* Tuning knobs, by name, process-wide (no counterpart in the reference).  "tail_records": once at most this many paths of a
- * batch are left, one kernel launch follows each of them to its end instead of running three launches per bounce
- * (0 switches that off; default 1048576, upper limit 16777216; scenes with meshes switch at four times the value).  "gpu_bvh_build": 1 builds the hierarchy of every mesh of 1024
- * triangles or more on the GPU when the next scenes are created (a linear BVH over Morton-ordered triangles: built in
- * milliseconds, costlier to walk than the host's surface-area tree); 0 (default) builds on the host.
- * "traverse_lanes": 1 (default) walks the hierarchies of queued rays with one
- * lane per ray; 4 with four lanes per ray, one per child box or triangle (slower as measured).  "specialised_kernels": 1 (default) traces a scene with the
- * kernels compiled for what it contains (no triangles, no texture coordinates, tables small enough for on-chip
- * copies, ...); 0 makes every scene use the general kernels that scenes with many objects get.  Unknown names and
- * values out of range fail with PTK_ERR_INVALID.  Results do not depend on any knob. */
+/* Tuning knobs, by name, process-wide (no counterpart in the reference).  Results do not depend on any of them.
+ * Unknown names and values out of range fail with PTK_ERR_INVALID.
+ *   "tail_records": once at most this many paths of a batch are left, one kernel launch follows each of them to
+ *     its end instead of running three launches per bounce (0 switches that off; default 1048576, upper limit
+ *     16777216; scenes with meshes switch at four times the value).
+ *   "launch_ahead": 0 to 7 (default 7), the bounces the host queues beyond the newest record count it has read back;
+ *     fewer makes the switch to the tail kernel prompt and leaves the device waiting for the host between bounces.
+ *   "batch_lanes": 1 traces the batches of a job one after the other; 2 cuts jobs of 2^21 paths or more into
+ *     batches of half the paths-in-flight limit and traces two at a time, each on a stream and a host thread of its
+ *     own; 0 (default) does that for scenes with meshes only.
+ *   "gpu_bvh_build": 1 builds the hierarchy of every mesh of 1024 triangles or more on the GPU when the next scenes
+ *     are created (a linear BVH over Morton-ordered triangles: built in milliseconds, costlier to walk than the
+ *     host's surface-area tree); 0 (default) builds on the host.
+ *   "traverse_lanes": 1 (default) walks the hierarchies of queued rays with one lane per ray; 4 with four lanes
+ *     per ray, one per child box or triangle (slower as measured).
+ *   "specialised_kernels": 1 (default) traces a scene with the kernels compiled for what it contains (no
+ *     triangles, no texture coordinates, tables small enough for on-chip copies, ...); 0 makes every scene use the
+ *     general kernels that scenes with many objects get. */
 int ptk_set_option(const char* name, int64_t value);
 
 /* Device self-test (no counterpart in the reference): sends `n_records` (1 to 2^22) path records through the

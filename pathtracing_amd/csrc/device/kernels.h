@@ -56,6 +56,9 @@ void launch_traverse(const LaunchContext& lc, uint32_t bound, const DevScene& sc
 void launch_bounce_resume(const LaunchContext& lc, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
                           const SampleResults& res, uint32_t* block_counts, uint32_t count_stride, unsigned long long* statistics,
                           const DeferQueues& queues);
+// block_counts[class][chunk] of the records `out` holds for the chunks of the list `info` describes (scenes with meshes)
+void launch_count_classes(const LaunchContext& lc, uint32_t bound, uint32_t rounds, const DevScene& sc, const PathPool& out, const BinInfo* info,
+                          uint32_t* block_counts, uint32_t count_stride);
 void launch_sum_statistics(hipStream_t s, const unsigned long long* slots, unsigned long long* totals);
 void launch_accumulate(hipStream_t s, const BatchParams& b, const SampleResults& res, double* image, double* position, double* normal,
                        unsigned long long* pixel_counters);

@@ -123,6 +123,32 @@ __global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathPool pool, const BinI
         if (classes[r] >= 0) list_out[counts[r][wave][classes[r]] + below[r]] = first + r * BLOCK + threadIdx.x;
 }
 
+// Counts, for every chunk of the list `info` describes, the classes of the records the bounce wrote for it:
+// block_counts[class][chunk], the input of the next class sort.  Scenes with meshes use it: there two kernels write
+// the records of a chunk (k_bounce, and k_bounce_resume for the vertices that waited for k_traverse), and counting
+// in k_bounce_resume took one atomic per wave, class and chunk on counters that share a few cache lines at any
+// moment, which the atomic unit of one L2 channel serialises.  One block per chunk; a pool's class bytes are 1 byte per record.
+__global__ __launch_bounds__(BLOCK) void k_count_classes(PathPool out, const BinInfo* info, uint32_t class_mask, uint32_t rounds,
+                                                         uint32_t* block_counts, uint32_t count_stride) {
+    __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
+    const ChunkTable table = chunk_table(info, rounds * BLOCK);
+    for (uint32_t chunk = blockIdx.x; chunk < table.first_chunk[N_CLASSES]; chunk += gridDim.x) {
+        int chunk_class;
+        uint32_t first, n;
+        locate_chunk(info, table, rounds * BLOCK, chunk, chunk_class, first, n);
+        uint32_t my_counts[N_CLASSES];
+#pragma unroll
+        for (int c = 0; c < N_CLASSES; c++) my_counts[c] = 0;
+        for (uint32_t qi = threadIdx.x; qi - threadIdx.x < n; qi += BLOCK) { // uniform trip count: the ballots need every lane
+            const int cls = qi < n ? static_cast<int>(out.cls[first + qi]) : -1;
+#pragma unroll
+            for (int c = 0; c < N_CLASSES; c++)
+                if ((class_mask >> c) & 1u) my_counts[c] += static_cast<uint32_t>(__popcll(__ballot(cls == c)));
+        }
+        store_chunk_counts(wave_counts, my_counts, block_counts, count_stride, chunk);
+    }
+}
+
 // Closest triangle for every queued ray: the meshes of the scene in object order, each hierarchy walked with
 // the shrinking t_max.  One ray per lane, and a wave that has lost enough of its rays takes new ones from the
 // queue: the number of nodes a ray visits varies widely (a few for most, hundreds for rays that graze a mesh),
@@ -700,6 +726,12 @@ void launch_bounce_resume(const LaunchContext& lc, uint32_t bound, const DevScen
     PTK_CASE(true, true, true);
     PTK_CASE(true, true, false);
 #undef PTK_CASE
+}
+
+void launch_count_classes(const LaunchContext& lc, uint32_t bound, uint32_t rounds, const DevScene& sc, const PathPool& out, const BinInfo* info,
+                          uint32_t* block_counts, uint32_t count_stride) {
+    hipLaunchKernelGGL(k_count_classes, dim3(chunk_blocks(bound, rounds)), dim3(BLOCK), 0, lc.stream, out, info, sc.class_mask, rounds,
+                       block_counts, count_stride);
 }
 
 void launch_sum_statistics(hipStream_t s, const unsigned long long* slots, unsigned long long* totals) {

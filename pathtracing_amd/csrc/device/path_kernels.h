@@ -816,14 +816,16 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
                 }
                 __syncthreads(); // queue_counts and queue_base are rewritten next round
             }
+            if (!DEFER) { // (a deferring kernel writes part of the chunk's records only: k_count_classes counts afterwards)
 #pragma unroll
-            for (int c = 0; c < N_CLASSES; c++)
-                if ((sc.class_mask >> c) & 1u) my_counts[c] += static_cast<uint32_t>(__popcll(__ballot(new_cls == c)));
+                for (int c = 0; c < N_CLASSES; c++)
+                    if ((sc.class_mask >> c) & 1u) my_counts[c] += static_cast<uint32_t>(__popcll(__ballot(new_cls == c)));
+            }
             if (!STAGE) cur = nxt;
             src = src_next;
             src_next = src_after;
         }
-        store_chunk_counts(wave_counts, my_counts, block_counts, count_stride, chunk);
+        if (!DEFER) store_chunk_counts(wave_counts, my_counts, block_counts, count_stride, chunk);
         add_block_statistics(statistics, wave_sums, stat);
     }
 }
@@ -899,8 +901,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
 
 // Finishes the deferred vertices: shades them again from the same records (same random numbers, so
 // the same two rays), takes the closest hits from the results (k_bounce's object scan, overridden by
-// k_traverse where a triangle is closer), and goes on as k_bounce does.  The class counts go to the chunk the
-// vertex came from, by atomics (one per wave and distinct chunk).
+// k_traverse where a triangle is closer), and goes on as k_bounce does.
 template<bool UV, bool PASS, bool CACHE>
 __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES : PTK_BOUNCE_WAVES) void k_bounce_resume(DevScene sc_global, BatchParams b, PathPool in,
                                                                                              PathPool out, SampleResults res,
@@ -960,17 +961,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
             }
         }
         const int new_cls = finish_vertex<true, UV, PASS>(sc, out, res, e.dst, v, alive, scatter_distance, hits[0], hits[1], st, stat);
-        // One atomic per distinct (class, chunk) among the lanes of the wave: neighbouring lanes mostly hold vertices
-        // of one chunk, and one atomic per lane made this kernel wait for the atomic unit of the L2.
-        uint32_t key = new_cls >= 0 ? static_cast<uint32_t>(new_cls) * count_stride + e.chunk : 0xFFFFFFFFu;
-        while (key != 0xFFFFFFFFu) {
-            const uint32_t first_key = __builtin_amdgcn_readfirstlane(key);
-            const unsigned long long same = __ballot(key == first_key);
-            if (key == first_key) {
-                if (lanes_below(same) == 0) atomicAdd(block_counts + first_key, static_cast<uint32_t>(__popcll(same)));
-                key = 0xFFFFFFFFu;
-            }
-        }
+        (void) new_cls; // the classes of a chunk's records are counted afterwards (k_count_classes)
         e = e_next;
         e_next = e_after;
         cur = nxt;

@@ -74,6 +74,16 @@ def test_frame_is_the_same_however_it_is_cut(which, request):
         finally:
             pt.set_option("tail_records", 1 << 20)
         assert all(np.array_equal(a, b) for a, b in zip(whole, other)), tail_records
+    # one batch at a time or two (each on a stream and a host thread of its own), the host far ahead of the device's record
+    # counts or not at all: bit-identical
+    for option, value, default in (("batch_lanes", 1, 0), ("batch_lanes", 2, 0), ("launch_ahead", 0, 7)):
+        pt.set_option(option, value)
+        try:
+            other, other_stats = render(hs, [pt.make_job(0, N, SPP, 0, 11)])
+        finally:
+            pt.set_option(option, default)
+        assert all(np.array_equal(a, b) for a, b in zip(whole, other)), (option, value)
+        assert (other_stats.paths, other_stats.vertices) == (stats.paths, stats.vertices), (option, value)
     # sample slices folded one after the other (what two GPUs would add up): equal up to rounding of the mean
     slices, _ = render(hs, [pt.make_job(0, N, SPP // 2, 0, 11), pt.make_job(0, N, SPP - SPP // 2, SPP // 2, 11)])
     np.testing.assert_allclose(slices[0], image, rtol=1e-12, atol=1e-15)
