@@ -232,6 +232,7 @@ def run_workload(pt, args, ds, workload, width, height, spp, steps, warmup, code
     offset = 0 if tiles else sample_slice(rank, world, total_spp * world)[0]
 
     profiled = {"steps": 0}
+    batch_lanes = int(dict(o.split("=", 1) for o in args.option).get("batch_lanes", 0))
     fam = {"k_bounce": [0.0, 0, 0], "k_bin": [0.0, 0, 0], "k_traverse": [0.0, 0, 0]}  # ms, bytes, launches
     other_ms = [0.0]
 
@@ -244,9 +245,13 @@ def run_workload(pt, args, ds, workload, width, height, spp, steps, warmup, code
     def step(i, timed=False):
         if timed and (i - warmup) % PROFILE_EVERY == 0:
             s0 = scene.stats()
+            # one batch at a time in a profiled step: with two in flight (scenes with meshes) the kernels of the two
+            # share the device, and an event pair around a launch times both
+            pt.set_option("batch_lanes", 1)
             pt.set_profiling(True)
             render_step(i)
             pt.set_profiling(False)
+            pt.set_option("batch_lanes", batch_lanes)
             s1 = scene.stats()
             profiled["steps"] += 1
             for k, f in (("k_bounce", "bounce"), ("k_bin", "bin"), ("k_traverse", "traverse")):

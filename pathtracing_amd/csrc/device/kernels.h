@@ -53,9 +53,8 @@ void launch_tail(const LaunchContext& lc, uint32_t bound, const DevScene& sc, co
 // Scenes with meshes, after launch_bounce: the hierarchy walks of the queued rays (statistics slots: [0] rays,
 // [1] nodes visited, [2] triangles tested), then the deferred vertices.
 void launch_traverse(const LaunchContext& lc, uint32_t bound, const DevScene& sc, const DeferQueues& queues, unsigned long long* statistics);
-void launch_bounce_resume(const LaunchContext& lc, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
-                          const SampleResults& res, uint32_t* block_counts, uint32_t count_stride, unsigned long long* statistics,
-                          const DeferQueues& queues);
+void launch_bounce_resume(const LaunchContext& lc, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& out,
+                          const SampleResults& res, unsigned long long* statistics, const DeferQueues& queues);
 // block_counts[class][chunk] of the records `out` holds for the chunks of the list `info` describes (scenes with meshes)
 void launch_count_classes(const LaunchContext& lc, uint32_t bound, uint32_t rounds, const DevScene& sc, const PathPool& out, const BinInfo* info,
                           uint32_t* block_counts, uint32_t count_stride);

@@ -711,15 +711,14 @@ void launch_traverse(const LaunchContext& lc, uint32_t bound, const DevScene& sc
     hipLaunchKernelGGL(k_traverse, grid, dim3(BLOCK), 0, s, sc, queues, statistics);
 }
 
-void launch_bounce_resume(const LaunchContext& lc, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
-                          const SampleResults& res, uint32_t* block_counts, uint32_t count_stride, unsigned long long* statistics,
-                          const DeferQueues& queues) {
+void launch_bounce_resume(const LaunchContext& lc, uint32_t bound, const DevScene& sc, const BatchParams& b, const PathPool& out,
+                          const SampleResults& res, unsigned long long* statistics, const DeferQueues& queues) {
     const hipStream_t s = lc.stream;
     const dim3 grid(min((bound + BLOCK - 1) / BLOCK + 1, static_cast<uint32_t>(STATISTICS_SLOTS)));
     const Variant v = variant_of(sc, lc.specialised);
 #define PTK_CASE(U, P, C)                                 \
     if (v.uv == U && v.pass == P && v.cache == C)         \
-        return launch_resume_variant<U, P, C>(s, grid, sc, b, in, out, res, block_counts, count_stride, statistics, queues)
+        return launch_resume_variant<U, P, C>(s, grid, sc, b, out, res, statistics, queues)
     PTK_CASE(false, false, true);
     PTK_CASE(false, true, true);
     PTK_CASE(true, false, true);

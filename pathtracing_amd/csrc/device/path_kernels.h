@@ -43,6 +43,10 @@ constexpr int BLOCK = 256;
 #ifndef PTK_BOUNCE_UV_WAVES
 #define PTK_BOUNCE_UV_WAVES 2
 #endif
+// k_bounce_resume without visibility marches through pass-through materials: little arithmetic, many loads
+#ifndef PTK_RESUME_WAVES
+#define PTK_RESUME_WAVES 4
+#endif
 #ifndef PTK_TRAVERSE_WAVES
 #define PTK_TRAVERSE_WAVES 4
 #endif
@@ -607,9 +611,8 @@ PTK_DEV void vertex_rays(const PathVertex& v, bool alive, double scatter_distanc
 // where does the new ray end), and the record of the continuing path.  Returns the class of the
 // next vertex, -1 when the path ended.
 template<bool TRIS, bool UV, bool PASS>
-PTK_DEV int finish_vertex(const DevScene& sc, const PathPool& out, const SampleResults& res, uint32_t dst, PathVertex& v, bool alive,
-                          double scatter_distance, const HitInfo& shadow_hit, const HitInfo& extension_hit, TraversalStack& st,
-                          uint32_t* stat) {
+PTK_DEV Vertex close_vertex(const DevScene& sc, PathVertex& v, bool alive, double scatter_distance, const HitInfo& shadow_hit,
+                            const HitInfo& extension_hit, TraversalStack& st, uint32_t* stat) {
     if (v.connect) {
         Rng march_rng{v.sh_key, 0};
         stat[2]++;
@@ -625,12 +628,17 @@ PTK_DEV int finish_vertex(const DevScene& sc, const PathPool& out, const SampleR
         nv = vertex_of(extension_hit, scatter_distance);
         if (nv.cls < 0 && !sc.background_is_black) v.color = v.color + v.thr * v3(sc.background);
     }
-    if (nv.cls < 0) { // the path ended here
-        flush_color(res, v.sid, v.color.x, v.color.y, v.color.z, v.has_hit);
-        out.cls[dst] = CLASS_DONE;
-        return -1;
-    }
-    stat[3]++;
+    return nv;
+}
+
+// Plane PL_HIT of the record of the path that continues from vertex v to the vertex nv.
+PTK_DEV void store_hit_plane(const PathPool& out, uint32_t dst, const PathVertex& v, double t) {
+    stu4(out, PL_HIT, dst, static_cast<uint32_t>(__double2loint(t)), static_cast<uint32_t>(__double2hiint(t)),
+         (v.depth + 1) | (v.ray_type << TYPE_SHIFT) | (v.has_hit ? FLAG_HAS_HIT : 0u) | (medium_bits_of(v) << 16), v.sid);
+}
+
+// The record of the path that continues from v; nv: the vertex its extension ray ends at.
+PTK_DEV void store_record(const PathPool& out, uint32_t dst, const PathVertex& v, const Vertex& nv) {
     st2(out, PL_RAY0, dst, v.point.x, v.point.y);
     st2(out, PL_RAY1, dst, v.point.z, v.n_dir.x);
     st2(out, PL_RAY2, dst, v.n_dir.y, v.n_dir.z);
@@ -639,11 +647,40 @@ PTK_DEV int finish_vertex(const DevScene& sc, const PathPool& out, const SampleR
     st2(out, PL_SAV0, dst, v.saved.x, v.saved.y);
     st2(out, PL_SAV1, dst, v.saved.z, v.color.x);
     st2(out, PL_COL, dst, v.color.y, v.color.z);
-    stu4(out, PL_HIT, dst, static_cast<uint32_t>(__double2loint(nv.t)), static_cast<uint32_t>(__double2hiint(nv.t)),
-         (v.depth + 1) | (v.ray_type << TYPE_SHIFT) | (v.has_hit ? FLAG_HAS_HIT : 0u) | (medium_bits_of(v) << 16), v.sid);
+    store_hit_plane(out, dst, v, nv.t);
     stu4(out, PL_IDS, dst, v.rng.ctr, static_cast<uint32_t>(nv.obj), static_cast<uint32_t>(nv.prim), 0u);
+}
+
+template<bool TRIS, bool UV, bool PASS>
+PTK_DEV int finish_vertex(const DevScene& sc, const PathPool& out, const SampleResults& res, uint32_t dst, PathVertex& v, bool alive,
+                          double scatter_distance, const HitInfo& shadow_hit, const HitInfo& extension_hit, TraversalStack& st,
+                          uint32_t* stat) {
+    const Vertex nv = close_vertex<TRIS, UV, PASS>(sc, v, alive, scatter_distance, shadow_hit, extension_hit, st, stat);
+    if (nv.cls < 0) { // the path ended here
+        flush_color(res, v.sid, v.color.x, v.color.y, v.color.z, v.has_hit);
+        out.cls[dst] = CLASS_DONE;
+        return -1;
+    }
+    stat[3]++;
+    store_record(out, dst, v, nv);
     out.cls[dst] = static_cast<uint8_t>(nv.cls);
     return nv.cls;
+}
+
+// A vertex whose rays wait for k_traverse: its record as far as it is known, and what k_bounce_resume needs beside it.
+PTK_DEV void store_pending(const PathPool& out, const DeferQueues& queues, uint32_t dst, const PathVertex& v, bool alive,
+                           double scatter_distance) {
+    Vertex unknown{0.0, -1, 0, -1};
+    store_record(out, dst, v, unknown);
+    double2* planes = reinterpret_cast<double2*>(queues.pending);
+    const uint64_t n = queues.capacity;
+    planes[dst] = make_double2(v.sh_dir.x, v.sh_dir.y);
+    planes[n + dst] = make_double2(v.sh_dir.z, v.sh_contrib.x);
+    planes[2 * n + dst] = make_double2(v.sh_contrib.y, v.sh_contrib.z);
+    planes[3 * n + dst] = make_double2(v.sh_dist, scatter_distance);
+    const uint32_t flags = (v.medium & 0xFFFFu) | (v.connect ? PENDING_CONNECT : 0u) | (alive ? PENDING_ALIVE : 0u);
+    planes[4 * n + dst] = make_double2(__longlong_as_double(static_cast<long long>(v.sh_key)),
+                                       __hiloint2double(static_cast<int>(flags), v.light_index));
 }
 
 // One vertex of every path: the loop body of raytrace (app/pathtracer.cpp:69-171) followed by the
@@ -770,6 +807,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
                 deferred = DEFER && (rays[0].needs_mesh || rays[1].needs_mesh);
                 origin = v.point;
                 if (!deferred) new_cls = finish_vertex<TRIS, UV, PASS>(sc, out, res, dst, v, alive, scatter_distance, hit_of(sc, rays[0]), hit_of(sc, rays[1]), st, stat);
+                else store_pending(out, queues, dst, v, alive, scatter_distance);
                 PTK_STAMP(1)
             }
             if (DEFER) { // queue the deferred vertices of this round and their rays: one atomic per block
@@ -803,7 +841,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
                         ray_slot += queue_counts[w][0];
                         vertex_slot += queue_counts[w][1];
                     }
-                    queues.vertices[vertex_slot] = DeferredVertex{dst, src, chunk, static_cast<uint32_t>(cls)};
+                    queues.vertices[vertex_slot] = dst;
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
                         if (rays[k].needs_mesh) {
@@ -899,15 +937,12 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
     add_block_statistics(statistics, wave_sums, stat);
 }
 
-// Finishes the deferred vertices: shades them again from the same records (same random numbers, so
-// the same two rays), takes the closest hits from the results (k_bounce's object scan, overridden by
-// k_traverse where a triangle is closer), and goes on as k_bounce does.
+// Finishes the deferred vertices: takes the closest hits of their two rays from the results (k_bounce's object scan,
+// overridden by k_traverse where a triangle is closer), runs the visibility march of the connection, and completes the
+// record k_bounce began (store_pending): where the extension ray ends, and the light the connection carried.
 template<bool UV, bool PASS, bool CACHE>
-__global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES : PTK_BOUNCE_WAVES) void k_bounce_resume(DevScene sc_global, BatchParams b, PathPool in,
-                                                                                             PathPool out, SampleResults res,
-                                                                                             uint32_t* block_counts, uint32_t count_stride,
-                                                                                             unsigned long long* statistics,
-                                                                                             DeferQueues queues) {
+__global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PASS ? PTK_BOUNCE_WAVES : PTK_RESUME_WAVES) void k_bounce_resume(DevScene sc_global, BatchParams b, PathPool out, SampleResults res,
+                                                                                              unsigned long long* statistics, DeferQueues queues) {
     __shared__ StackEntry lds_stack[PASS ? LDS_STACK_DEPTH * BLOCK : 1];
     __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
     PTK_TRAVERSAL_STACK(st, lds_stack, sc_global);
@@ -916,34 +951,33 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
     __shared__ double lds_scene[CACHE ? LDS_SCENE_DOUBLES : 1];
     const DevScene sc = stage_scene<CACHE>(sc_global, lds_scene);
     uint32_t stat[N_STATISTICS] = {};
-    // Software pipeline over the vertices of a lane, as in k_bounce: the next vertex's record and results are
-    // requested in the middle of the current one, its queue entry one step earlier still.
-    const uint32_t stride = gridDim.x * BLOCK;
-    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    DeferredVertex e{}, e_next{};
-    Record cur{};
-    RayResult found[2] = {};
-    if (i < n) {
-        e = queues.vertices[i];
-        cur = load_record(in, e.src);
-        found[0] = queues.results[2 * e.dst];
-        found[1] = queues.results[2 * e.dst + 1];
-    }
-    if (i + stride < n) e_next = queues.vertices[i + stride];
-    for (; i < n; i += stride) {
-        PathVertex v;
-        const bool alive = shade_record<true, UV>(sc, b, res, cur, static_cast<int>(e.cls), v);
-        Record nxt{};
-        RayResult found_next[2] = {};
-        DeferredVertex e_after{};
-        if (i + stride < n) {
-            nxt = load_record(in, e_next.src);
-            found_next[0] = queues.results[2 * e_next.dst];
-            found_next[1] = queues.results[2 * e_next.dst + 1];
+    const double2* planes = reinterpret_cast<const double2*>(queues.pending);
+    const uint64_t cap = queues.capacity;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const uint32_t dst = queues.vertices[i];
+        const RayResult found[2] = {queues.results[2 * dst], queues.results[2 * dst + 1]};
+        const double2 p0 = planes[dst], p1 = planes[cap + dst], p2 = planes[2 * cap + dst], p3 = planes[3 * cap + dst], p4 = planes[4 * cap + dst];
+        const double2 r0 = ld2(out, PL_RAY0, dst), r1 = ld2(out, PL_RAY1, dst), s1 = ld2(out, PL_SAV1, dst), cc = ld2(out, PL_COL, dst);
+        const uint4 hit = ldu4(out, PL_HIT, dst), ids = ldu4(out, PL_IDS, dst);
+        const uint32_t flags = static_cast<uint32_t>(__double2hiint(p4.y));
+        PathVertex v{};
+        v.point = v3(r0.x, r0.y, r1.x);
+        v.color = v3(s1.y, cc.x, cc.y);
+        v.sid = hit.w;
+        v.has_hit = (hit.z & FLAG_HAS_HIT) != 0;
+        v.medium = flags & 0xFFFFu;
+        v.connect = (flags & PENDING_CONNECT) != 0;
+        v.light_index = __double2loint(p4.y);
+        v.sh_dir = v3(p0.x, p0.y, p1.x);
+        v.sh_contrib = v3(p1.y, p2.x, p2.y);
+        v.sh_dist = p3.x;
+        v.sh_key = static_cast<uint64_t>(__double_as_longlong(p4.x));
+        if (!sc.background_is_black) { // the throughput matters only to a path that leaves the scene
+            const double2 t0 = ld2(out, PL_THR0, dst), t1 = ld2(out, PL_THR1, dst);
+            v.thr = v3(t0.x, t0.y, t1.x);
         }
-        if (i + 2 * stride < n) e_after = queues.vertices[i + 2 * stride];
-        double scatter_distance = INF;
-        if (alive) scatter_distance = free_flight_distance(sc, b, medium_bits_of(v), v.sid, v.rng.ctr);
+        const bool alive = (flags & PENDING_ALIVE) != 0;
+        const double scatter_distance = p3.y;
         // The closest hits of the two rays are in the results: what k_bounce's object scan found, replaced by
         // k_traverse where a triangle of a mesh is closer (it starts from the scan's distance and object).
         HitInfo hits[2];
@@ -960,13 +994,21 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
                 hits[k].cls = o.mat.type;
             }
         }
-        const int new_cls = finish_vertex<true, UV, PASS>(sc, out, res, e.dst, v, alive, scatter_distance, hits[0], hits[1], st, stat);
-        (void) new_cls; // the classes of a chunk's records are counted afterwards (k_count_classes)
-        e = e_next;
-        e_next = e_after;
-        cur = nxt;
-        found[0] = found_next[0];
-        found[1] = found_next[1];
+        const Vertex nv = close_vertex<true, UV, PASS>(sc, v, alive, scatter_distance, hits[0], hits[1], st, stat);
+        if (nv.cls < 0) { // the path ended here
+            flush_color(res, v.sid, v.color.x, v.color.y, v.color.z, v.has_hit);
+            out.cls[dst] = CLASS_DONE;
+        }
+        else {
+            stat[3]++;
+            if (v.connect) {
+                st2(out, PL_SAV1, dst, s1.x, v.color.x);
+                st2(out, PL_COL, dst, v.color.y, v.color.z);
+            }
+            stu4(out, PL_HIT, dst, static_cast<uint32_t>(__double2loint(nv.t)), static_cast<uint32_t>(__double2hiint(nv.t)), hit.z, hit.w);
+            stu4(out, PL_IDS, dst, ids.x, static_cast<uint32_t>(nv.obj), static_cast<uint32_t>(nv.prim), 0u);
+            out.cls[dst] = static_cast<uint8_t>(nv.cls);
+        }
     }
     add_block_statistics(statistics, wave_sums, stat);
 }

@@ -216,8 +216,10 @@ struct PathPool {
 // and extension rays miss the bounds of every mesh; the others it defers: it queues their rays
 // (with t_max already cut to the closest hit among the other objects) and the vertex itself.
 // k_traverse walks the hierarchies for the queued rays, one ray per lane, so that lanes and waves
-// are filled with rays that really traverse; k_bounce_resume shades the deferred vertices again (same
-// record, same random numbers, hence the same rays) and finishes them with the traversal results.
+// are filled with rays that really traverse; k_bounce_resume finishes the deferred vertices with the
+// traversal results.  A deferred vertex is shaded once: k_bounce writes the record of the continuing path
+// as far as it is known (everything but where the extension ray ends and the light the connection
+// carries) and, beside it, what the rest needs (PENDING_PLANES planes indexed like the records).
 struct RayRequest { // 64 bytes
     double ox, oy, oz, dx, dy, dz;
     double limit;    // t_max: the distance of the closest hit among the objects that are not meshes
@@ -228,16 +230,20 @@ struct RayResult { // 16 bytes: the closest hit of a deferred vertex's ray; obj 
     double t;
     int32_t obj, prim; // prim: the triangle when obj is a mesh
 };
-struct DeferredVertex { // 16 bytes
-    uint32_t dst, src; // record positions in the output and input pools
-    uint32_t chunk;    // chunk of the list it belongs to (its class count goes there)
-    uint32_t cls;
-};
+// What k_bounce_resume needs of a deferred vertex beyond its provisional record, 16-byte planes of [capacity]
+// indexed by the record's position in the output pool:
+//   0: sh_dir.x, sh_dir.y   1: sh_dir.z, sh_contrib.x   2: sh_contrib.y, sh_contrib.z   3: sh_dist, scatter_distance
+//   4: sh_key, then two 32-bit words: light_index, and the vertex's medium (low 16 bits, MEDIUM_NONE for none) with
+//      PENDING_CONNECT / PENDING_ALIVE
+constexpr int PENDING_PLANES = 5;
+constexpr uint32_t PENDING_CONNECT = 1u << 16, PENDING_ALIVE = 1u << 17;
 struct DeferQueues {
     RayRequest* rays;
     RayResult* results;       // [2 * capacity], indexed by RayRequest::slot
-    DeferredVertex* vertices;
+    uint32_t* vertices;       // positions in the output pool of the deferred vertices
     uint32_t* counters;       // [4]: [0] rays queued, [1] vertices queued, [2] rays handed out by k_traverse
+    double* pending;          // [PENDING_PLANES][capacity][2]
+    uint64_t capacity;        // records per plane of `pending`
 };
 
 // Per-sample results (PixelData, app/pathtracer.cpp:20-24), indexed by the sample's batch index

@@ -25,8 +25,7 @@ void launch_tail_variant(hipStream_t s, dim3 grid, const DevScene& sc, const Bat
                          const SampleResults& res, const uint32_t* list, BinInfo* info, unsigned long long* statistics);
 
 template<bool UV, bool PASS, bool CACHE>
-void launch_resume_variant(hipStream_t s, dim3 grid, const DevScene& sc, const BatchParams& b, const PathPool& in, const PathPool& out,
-                           const SampleResults& res, uint32_t* block_counts, uint32_t count_stride, unsigned long long* statistics,
-                           const DeferQueues& queues);
+void launch_resume_variant(hipStream_t s, dim3 grid, const DevScene& sc, const BatchParams& b, const PathPool& out, const SampleResults& res,
+                           unsigned long long* statistics, const DeferQueues& queues);
 
 } // namespace ptk

@@ -23,9 +23,7 @@
 
 #define PTK_RESUME_VARIANT(U, P, C)                                                                                                    \
     template<>                                                                                                                         \
-    void launch_resume_variant<U, P, C>(hipStream_t s, dim3 grid, const DevScene& sc, const BatchParams& b, const PathPool& in,        \
-                                        const PathPool& out, const SampleResults& res, uint32_t* block_counts, uint32_t count_stride,  \
-                                        unsigned long long* statistics, const DeferQueues& queues) {                                   \
-        hipLaunchKernelGGL((k_bounce_resume<U, P, C>), grid, dim3(BLOCK), 0, s, sc, b, in, out, res, block_counts, count_stride,       \
-                           statistics, queues);                                                                                        \
+    void launch_resume_variant<U, P, C>(hipStream_t s, dim3 grid, const DevScene& sc, const BatchParams& b, const PathPool& out,       \
+                                        const SampleResults& res, unsigned long long* statistics, const DeferQueues& queues) {         \
+        hipLaunchKernelGGL((k_bounce_resume<U, P, C>), grid, dim3(BLOCK), 0, s, sc, b, out, res, statistics, queues);                  \
     }

@@ -302,6 +302,8 @@ int ensure_capacity(const PtkScene* s, BatchLane& lane, int64_t paths) {
         HIP_TRY(b.alloc(&lane.queues.results, 2 * n));
         HIP_TRY(b.alloc(&lane.queues.vertices, n));
         HIP_TRY(b.alloc(&lane.queues.counters, 4));
+        HIP_TRY(b.alloc(&lane.queues.pending, n * PENDING_PLANES * 2));
+        lane.queues.capacity = n;
     }
     lane.count_stride = (chunk_capacity(static_cast<uint32_t>(n)) + 3u) & ~3u; // one entry per chunk; rows stay 16-byte aligned
     HIP_TRY(b.alloc(&lane.block_counts, static_cast<size_t>(lane.count_stride) * N_CLASSES));
@@ -477,8 +479,7 @@ int trace_batch(PtkScene* s, BatchLane& lane, const BatchParams& b) {
             launch_traverse(lc, bound, s->dev, lane.queues, lane.d_statistics + STATISTICS_SET);
             timer.end();
             timer.begin(0);
-            launch_bounce_resume(lc, bound, s->dev, b, current, next, lane.results, lane.block_counts, lane.count_stride, lane.d_statistics,
-                                 lane.queues);
+            launch_bounce_resume(lc, bound, s->dev, b, next, lane.results, lane.d_statistics, lane.queues);
             launch_count_classes(lc, bound, pool_rounds, s->dev, next, info, lane.block_counts, lane.count_stride);
             timer.end();
             st.traverse_launches++;
