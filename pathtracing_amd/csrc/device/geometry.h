@@ -171,9 +171,8 @@ PTK_DEV SlabRay slab_ray(const V3& org, const V3& dir, float bound_abs) {
 }
 
 // One inner node (already in registers: `n`): tests its four boxes, pushes the children that can hold something
-// closer than t_best except the nearest, and returns the nearest (or the next entry of the stack when no child
-// qualifies).
-// visit_inner_children leaves the last step to the caller: `pop` is set when no child qualifies.
+// closer than t_best except the nearest, and returns the nearest; `pop` is set when no child qualifies (the caller
+// then takes the next entry of the stack).
 PTK_DEV int32_t visit_inner_children(const BvhNode4& n, const SlabRay& r, double t_best, TraversalStack& st, bool& pop) {
     const float FAR = __builtin_inff();
     st.nodes_visited++;
@@ -213,48 +212,66 @@ PTK_DEV int32_t visit_inner_children(const BvhNode4& n, const SlabRay& r, double
     pop = !(tn[0] < FAR);
     return ch[0];
 }
-PTK_DEV int32_t visit_inner(const BvhNode4& n, const SlabRay& r, double t_best, TraversalStack& st) {
-    bool pop;
-    const int32_t nearest = visit_inner_children(n, r, t_best, st, pop);
-    return pop ? pop_closer(st, t_best) : nearest;
-}
 
-// One leaf: the exact test of its triangles; returns whether one of them became the closest hit.
-PTK_DEV bool visit_leaf(const DevScene& sc, int32_t leaf, int64_t first_tri, const V3& org, const RayPrep& rp, double& t_best,
-                        int& prim_best, TraversalStack& st) {
-    const uint32_t code = static_cast<uint32_t>(~leaf);
-    const int64_t first = first_tri + (code >> 3);
-    const int count = static_cast<int>(code & 7u) + 1;
-    st.triangles_tested += count;
-    bool found = false;
-    for (int i = 0; i < count; i++) {
+// Every pass of the loop takes the ray one step further: the box tests of an inner node's four children, or one
+// triangle of a leaf.  The lanes of a wave that hold an inner node and those that hold a leaf fetch with the same
+// load instructions (a node is 112 bytes, a triangle 72: five 16-byte loads serve both, two more the nodes), so a
+// pass waits for memory once.  (sc.tri_hot ends in one spare element: the fifth load reads 8 bytes past a triangle.)
+// Returns node, tri_i for the next pass; node == BVH_EMPTY: the walk is over.
+struct WalkStep {
+    bool found;     // a triangle became the closest hit in this pass
+    int32_t prim;   // that triangle
+};
+PTK_DEV WalkStep walk_step(const DevScene& sc, int32_t& node, int& tri_i, int64_t first_tri, const V3& org, const RayPrep& rp,
+                           const SlabRay& slab, double& t_best, TraversalStack& st) {
+    WalkStep out{false, -1};
+    const bool is_inner = node >= 0;
+    const uint32_t code = static_cast<uint32_t>(~node);
+    const int64_t tri = first_tri + (code >> 3) + tri_i;
+    const double* src = is_inner ? reinterpret_cast<const double*>(sc.nodes + node) : reinterpret_cast<const double*>(sc.tri_hot + tri);
+    double raw[14];
+#pragma unroll
+    for (int k = 0; k < 5; k++) __builtin_memcpy(raw + 2 * k, src + 2 * k, 16);
+    bool pop = false; // the lane's next node comes from its stack
+    if (is_inner) {
+#pragma unroll
+        for (int k = 5; k < 7; k++) __builtin_memcpy(raw + 2 * k, src + 2 * k, 16);
+        BvhNode4 nd;
+        __builtin_memcpy(&nd, raw, 112);
+        node = visit_inner_children(nd, slab, t_best, st, pop);
+    }
+    else {
+        TriHot th;
+        __builtin_memcpy(&th, raw, sizeof(TriHot));
+        st.triangles_tested++;
         double d;
-        if (triangle_hit(sc.tri_hot[first + i], org, rp, t_best, d) && d > EPSILON && d < t_best) {
+        if (triangle_hit(th, org, rp, t_best, d) && d > EPSILON && d < t_best) {
             t_best = d;
-            prim_best = static_cast<int>(first + i);
-            found = true;
+            out.found = true;
+            out.prim = static_cast<int32_t>(tri);
+        }
+        if (++tri_i > static_cast<int>(code & 7u)) { // the leaf is done
+            pop = true;
+            tri_i = 0;
         }
     }
-    return found;
+    if (pop) node = pop_closer(st, t_best);
+    return out;
 }
 
-// The walk alternates between two loops: down through inner nodes until the lane holds a leaf, then through
-// leaves until it holds an inner node again.  The lanes of a wave then execute the box tests together and the
-// triangle tests together.
 PTK_DEV void mesh_closest_hit(const DevScene& sc, int32_t bvh_root, int64_t first_tri, const V3& org, const V3& dir,
                               const RayPrep& rp, double& t_best, int& prim_best, TraversalStack& st, float bound_abs,
                               bool any_hit = false) {
-    if (bvh_root < 0) return;
     const SlabRay r = slab_ray(org, dir, bound_abs);
     st.sp = 0;
-    int32_t node = bvh_root;
-    for (;;) {
-        while (node >= 0) node = visit_inner(sc.nodes[node], r, t_best, st);
-        while (node < 0 && node != BVH_EMPTY) {
-            if (visit_leaf(sc, node, first_tri, org, rp, t_best, prim_best, st) && any_hit) return;
-            node = pop_closer(st, t_best);
+    int32_t node = bvh_root < 0 ? BVH_EMPTY : bvh_root; // (a mesh without triangles has no root)
+    int tri_i = 0;
+    while (node != BVH_EMPTY) {
+        const WalkStep step = walk_step(sc, node, tri_i, first_tri, org, rp, r, t_best, st);
+        if (step.found) {
+            prim_best = step.prim;
+            if (any_hit) return;
         }
-        if (node == BVH_EMPTY) return;
     }
 }
 

@@ -155,10 +155,8 @@ __global__ __launch_bounds__(BLOCK) void k_count_classes(PathPool out, const Bin
 // and a wave that kept its 64 rays until the last one finished ran mostly empty.  The grid is sized to fill the
 // device once; every wave leaves when the queue is empty and its own rays are done.
 //
-// Every pass of the loop takes each ray one step further: the box tests of an inner node's four children, or one
-// triangle of a leaf.  Lanes of both kinds fetch with the same load instructions (a node is 112 bytes, a triangle
-// 72: five 16-byte loads serve both, two more the nodes), so a pass waits for memory once, and 50 of 64 lanes do
-// work in it.  (Measured on one MI355X, 1,048,576-triangle workload, per 8-spp frame: 22.6 ms, against 31 ms for a
+// Every pass of the loop takes each ray one step further (walk_step, geometry.h): the box tests of an inner node's
+// four children, or one triangle of a leaf, and 50 of 64 lanes do work in it.  (Measured on one MI355X, 1,048,576-triangle workload, per 8-spp frame: 22.6 ms, against 31 ms for a
 // descent through inner nodes until every lane holds a leaf followed by a loop over the leaves, where 12 of 64
 // lanes are active per box test, and 24.6 ms for one step of the more numerous kind per pass.)
 // queues.counters: [0] rays queued, [2] next ray to hand out (zero at launch).
@@ -260,44 +258,17 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_WAVES) void 
         if (lanes_below(__ballot(true)) == 0) stat[3]++; // passes of the wave
         stat[7] += has_ray ? 1 : 0;                      // lanes that held a ray in them
 #endif
-        const bool is_inner = node >= 0, is_leaf = node < 0 && node != BVH_EMPTY;
-        if (is_inner || is_leaf) {
-            const uint32_t code = static_cast<uint32_t>(~node);
-            const int64_t tri = first_tri + (code >> 3) + tri_i;
-            const double* src = is_inner ? reinterpret_cast<const double*>(sc.nodes + node) : reinterpret_cast<const double*>(sc.tri_hot + tri);
-            double raw[14];
-#pragma unroll
-            for (int k = 0; k < 5; k++) __builtin_memcpy(raw + 2 * k, src + 2 * k, 16);
-            bool pop = false; // the lane's next node comes from its stack
-            if (is_inner) {
-#pragma unroll
-                for (int k = 5; k < 7; k++) __builtin_memcpy(raw + 2 * k, src + 2 * k, 16);
-                BvhNode4 nd;
-                __builtin_memcpy(&nd, raw, 112);
-                node = visit_inner_children(nd, slab, best.t, st, pop);
-            }
-            else {
-                TriHot th;
-                __builtin_memcpy(&th, raw, sizeof(TriHot));
-                st.triangles_tested++;
-                double d;
-                const bool found = triangle_hit(th, org, rp, best.t, d) && d > EPSILON && d < best.t;
-                if (found) {
-                    best.t = d;
-                    best.obj = object;
-                    best.prim = static_cast<int32_t>(tri);
-                }
-                if (found && any_hit) { // nothing else matters for this ray
+        if (node != BVH_EMPTY) { // (a lane without a ray holds BVH_EMPTY too)
+            const WalkStep step = walk_step(sc, node, tri_i, first_tri, org, rp, slab, best.t, st);
+            if (step.found) {
+                best.obj = object;
+                best.prim = step.prim;
+                if (any_hit) { // nothing else matters for this ray
                     mesh = sc.n_meshes;
                     node = BVH_EMPTY;
                     tri_i = 0;
                 }
-                else if (++tri_i > static_cast<int>(code & 7u)) { // the leaf is done
-                    pop = true;
-                    tri_i = 0;
-                }
             }
-            if (pop) node = pop_closer(st, best.t);
         }
     }
     stat[1] = st.nodes_visited;
