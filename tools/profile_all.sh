@@ -7,7 +7,8 @@ rnd=$1
 R=${GRAFT_REPO_ROOT:-$PWD}
 for w in example mesh room cloud; do
   steps=16; [ "$w" = example ] || steps=8
-  "$R/tools/profile_round.sh" "${rnd}_$w" --workload $w --steps $steps
+  # one batch at a time (batch_lanes=1): with two in flight the kernels of the two share the device and their durations say less
+  "$R/tools/profile_round.sh" "${rnd}_$w" --workload $w --steps $steps --option batch_lanes=1
 done
 mkdir -p "$R/gpurun_out/${rnd}_denoise"
 cd /tmp && export TMPDIR=/tmp
