@@ -173,9 +173,28 @@ PTK_DEV SlabRay slab_ray(const V3& org, const V3& dir, float bound_abs) {
 // One inner node (already in registers: `n`): tests its four boxes, pushes the children that can hold something
 // closer than t_best except the nearest, and returns the nearest; `pop` is set when no child qualifies (the caller
 // then takes the next entry of the stack).
-PTK_DEV int32_t visit_inner_children(const BvhNode4& n, const SlabRay& r, double t_best, TraversalStack& st, bool& pop) {
+template<bool NARROW>
+PTK_DEV int32_t visit_inner_children(const BvhNode4& n, const SlabRay& ray, double t_best, TraversalStack& st, bool& pop) {
     const float FAR = __builtin_inff();
     st.nodes_visited++;
+    // NARROW (k_traverse): the ray's constants live as single registers between visits and are widened to pairs here, on
+    // every visit; the empty asm keeps the compiler from widening them once, outside the walk's loop, where the pairs
+    // would hold nine more registers for the whole walk (k_traverse then fits five waves per SIMD instead of four).
+    SlabRay r = ray;
+    if (NARROW) {
+        float nox = ray.nox[0], noy = ray.noy[0], noz = ray.noz[0], ix = ray.ix[0], iy = ray.iy[0], iz = ray.iz[0], px = ray.px[0],
+              py = ray.py[0], pz = ray.pz[0];
+        asm volatile("" : "+v"(nox), "+v"(noy), "+v"(noz), "+v"(ix), "+v"(iy), "+v"(iz), "+v"(px), "+v"(py), "+v"(pz));
+        r.nox = Float2{nox, nox};
+        r.noy = Float2{noy, noy};
+        r.noz = Float2{noz, noz};
+        r.ix = Float2{ix, ix};
+        r.iy = Float2{iy, iy};
+        r.iz = Float2{iz, iz};
+        r.px = Float2{px, px};
+        r.py = Float2{py, py};
+        r.pz = Float2{pz, pz};
+    }
     float tn[4];
     int32_t ch[4];
 #pragma unroll
@@ -222,6 +241,7 @@ struct WalkStep {
     bool found;     // a triangle became the closest hit in this pass
     int32_t prim;   // that triangle
 };
+template<bool NARROW>
 PTK_DEV WalkStep walk_step(const DevScene& sc, int32_t& node, int& tri_i, int64_t first_tri, const V3& org, const RayPrep& rp,
                            const SlabRay& slab, double& t_best, TraversalStack& st) {
     WalkStep out{false, -1};
@@ -238,7 +258,7 @@ PTK_DEV WalkStep walk_step(const DevScene& sc, int32_t& node, int& tri_i, int64_
         for (int k = 5; k < 7; k++) __builtin_memcpy(raw + 2 * k, src + 2 * k, 16);
         BvhNode4 nd;
         __builtin_memcpy(&nd, raw, 112);
-        node = visit_inner_children(nd, slab, t_best, st, pop);
+        node = visit_inner_children<NARROW>(nd, slab, t_best, st, pop);
     }
     else {
         TriHot th;
@@ -267,7 +287,7 @@ PTK_DEV void mesh_closest_hit(const DevScene& sc, int32_t bvh_root, int64_t firs
     int32_t node = bvh_root < 0 ? BVH_EMPTY : bvh_root; // (a mesh without triangles has no root)
     int tri_i = 0;
     while (node != BVH_EMPTY) {
-        const WalkStep step = walk_step(sc, node, tri_i, first_tri, org, rp, r, t_best, st);
+        const WalkStep step = walk_step<false>(sc, node, tri_i, first_tri, org, rp, r, t_best, st);
         if (step.found) {
             prim_best = step.prim;
             if (any_hit) return;

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_WAVES) void 
         stat[7] += has_ray ? 1 : 0;                      // lanes that held a ray in them
 #endif
         if (node != BVH_EMPTY) { // (a lane without a ray holds BVH_EMPTY too)
-            const WalkStep step = walk_step(sc, node, tri_i, first_tri, org, rp, slab, best.t, st);
+            const WalkStep step = walk_step<true>(sc, node, tri_i, first_tri, org, rp, slab, best.t, st);
             if (step.found) {
                 best.obj = object;
                 best.prim = step.prim;

@@ -48,7 +48,7 @@ constexpr int BLOCK = 256;
 #define PTK_RESUME_WAVES 4
 #endif
 #ifndef PTK_TRAVERSE_WAVES
-#define PTK_TRAVERSE_WAVES 4
+#define PTK_TRAVERSE_WAVES 5
 #endif
 #ifndef PTK_TRAVERSE_QUAD_WAVES
 #define PTK_TRAVERSE_QUAD_WAVES 5

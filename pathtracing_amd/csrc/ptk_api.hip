@@ -323,6 +323,7 @@ constexpr uint64_t BIN_BYTES_PER_VERTEX = 4;                        // list entr
 constexpr uint64_t GENERATE_BYTES_PER_PATH = RECORD_BYTES + 1;          // record, class out
 constexpr uint64_t ACCUMULATE_BYTES_PER_PATH = 32 + 3 * 16;         // results in
 constexpr uint64_t TRAVERSE_BYTES_PER_RAY = sizeof(RayRequest) + sizeof(RayResult);
+constexpr uint64_t NODE_BYTES = sizeof(BvhNode4) - 16; // without the padding
 // two sets of statistics slots (k_bounce and k_bounce_resume; k_traverse), then their totals
 constexpr size_t STATISTICS_SET = static_cast<size_t>(N_STATISTICS) * STATISTICS_SLOTS;
 constexpr size_t STATISTICS_VALUES = 2 * (STATISTICS_SET + N_STATISTICS);
@@ -509,13 +510,13 @@ int trace_batch(PtkScene* s, BatchLane& lane, const BatchParams& b) {
     std::fprintf(stderr, "wave-cycles/16: shade %llu, rays %llu; vertices %llu, rays %llu\n", lane.h_rays[6], lane.h_rays[7],
                  (unsigned long long) sum_vertices, (unsigned long long) (segments + extensions));
 #endif
-    if (s->dev.has_meshes) { // k_traverse: ray request in, result out, 128-byte nodes, 72-byte triangle vertices
+    if (s->dev.has_meshes) { // k_traverse: ray request in, result out, the 112 bytes of a node that hold boxes and children, 72-byte triangle vertices
         const unsigned long long* t = lane.h_rays + N_STATISTICS;
 #ifdef PTK_TRAVERSE_PROBE
         std::fprintf(stderr, "traverse probe: rays %llu, nodes %llu, triangles %llu, passes of a wave %llu, lanes with a ray in them %llu\n",
                      t[0], t[1], t[2], t[3], t[7]);
 #endif
-        const uint64_t tb = TRAVERSE_BYTES_PER_RAY * t[0] + sizeof(BvhNode4) * t[1] + sizeof(TriHot) * t[2];
+        const uint64_t tb = TRAVERSE_BYTES_PER_RAY * t[0] + NODE_BYTES * t[1] + sizeof(TriHot) * t[2];
         st.traversed_rays += t[0];
         st.nodes_visited += t[1];
         st.triangles_tested += t[2];
