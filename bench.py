@@ -290,8 +290,8 @@ def run_workload(pt, args, ds, workload, width, height, spp, steps, warmup, code
     value = total_paths / elapsed / 1e6
 
     # The dominant kernel, timed with HIP events on the library's stream over the profiled steps of this timed
-    # region and named as rocprofv3 shows it: k_bounce (every path vertex: shading, shadow ray, extension ray; in
-    # scenes with meshes its time includes the resume pass) or, in scenes with meshes, k_traverse.
+    # region and named as rocprofv3 shows it: k_bounce (every path vertex: shading, shadow ray, extension ray) or, in
+    # scenes with meshes, k_traverse when it takes longer.
     traverse = fam["k_traverse"][0] > fam["k_bounce"][0]
     kernel = "ptk::k_traverse" if traverse else scene.bounce_kernel()
     d_ms, d_bytes, d_launches = fam["k_traverse"] if traverse else fam["k_bounce"]

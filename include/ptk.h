@@ -187,9 +187,10 @@ typedef struct PtkStats {
     uint64_t vertices;      /* surface + scatter vertices shaded */
     uint64_t bounce_launch_rounds;
     uint64_t algorithmic_bytes; /* path-state/queue bytes the kernels are specified to move */
-    /* Kernel families: bounce = k_bounce and k_bounce_resume (shading, shadow ray and extension ray
+    /* Kernel families: bounce = k_bounce and the tail kernel (shading, shadow ray and extension ray
      * of one path vertex), bin = the class sort between bounces, traverse = the hierarchy walks of
-     * scenes with meshes (k_traverse). */
+     * scenes with meshes (k_traverse), other = the rest (camera rays, and in scenes with meshes the
+     * pass that completes the vertices which waited for k_traverse). */
     double bounce_ms, bin_ms, other_ms, traverse_ms; /* device time per family, HIP events, while profiling is on */
     uint64_t bounce_launches, bin_launches, traverse_launches;
     uint64_t bounce_bytes, bin_bytes, traverse_bytes; /* algorithmic bytes per family */

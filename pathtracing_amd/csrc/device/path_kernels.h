@@ -670,13 +670,24 @@ PTK_DEV int finish_vertex(const DevScene& sc, const PathPool& out, const SampleR
 // A vertex whose rays wait for k_traverse: its record as far as it is known, and what k_bounce_resume needs beside it.
 PTK_DEV void store_pending(const PathPool& out, const DeferQueues& queues, uint32_t dst, const PathVertex& v, bool alive,
                            double scatter_distance) {
-    Vertex unknown{0.0, -1, 0, -1};
-    store_record(out, dst, v, unknown);
+    if (alive) {
+        Vertex unknown{0.0, -1, 0, -1};
+        store_record(out, dst, v, unknown);
+    }
+    else { // the path ends in k_bounce_resume, which needs where the vertex is, the light gathered so far and the sample index
+        st2(out, PL_RAY0, dst, v.point.x, v.point.y);
+        st2(out, PL_RAY1, dst, v.point.z, v.n_dir.x);
+        st2(out, PL_SAV1, dst, v.saved.z, v.color.x);
+        st2(out, PL_COL, dst, v.color.y, v.color.z);
+        store_hit_plane(out, dst, v, 0.0);
+    }
     double2* planes = reinterpret_cast<double2*>(queues.pending);
     const uint64_t n = queues.capacity;
-    planes[dst] = make_double2(v.sh_dir.x, v.sh_dir.y);
-    planes[n + dst] = make_double2(v.sh_dir.z, v.sh_contrib.x);
-    planes[2 * n + dst] = make_double2(v.sh_contrib.y, v.sh_contrib.z);
+    if (v.connect) {
+        planes[dst] = make_double2(v.sh_dir.x, v.sh_dir.y);
+        planes[n + dst] = make_double2(v.sh_dir.z, v.sh_contrib.x);
+        planes[2 * n + dst] = make_double2(v.sh_contrib.y, v.sh_contrib.z);
+    }
     planes[3 * n + dst] = make_double2(v.sh_dist, scatter_distance);
     const uint32_t flags = (v.medium & 0xFFFFu) | (v.connect ? PENDING_CONNECT : 0u) | (alive ? PENDING_ALIVE : 0u);
     planes[4 * n + dst] = make_double2(__longlong_as_double(static_cast<long long>(v.sh_key)),
@@ -956,10 +967,16 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PASS ? PTK_BOUNCE_WAVES :
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         const uint32_t dst = queues.vertices[i];
         const RayResult found[2] = {queues.results[2 * dst], queues.results[2 * dst + 1]};
-        const double2 p0 = planes[dst], p1 = planes[cap + dst], p2 = planes[2 * cap + dst], p3 = planes[3 * cap + dst], p4 = planes[4 * cap + dst];
+        const double2 p3 = planes[3 * cap + dst], p4 = planes[4 * cap + dst];
         const double2 r0 = ld2(out, PL_RAY0, dst), r1 = ld2(out, PL_RAY1, dst), s1 = ld2(out, PL_SAV1, dst), cc = ld2(out, PL_COL, dst);
-        const uint4 hit = ldu4(out, PL_HIT, dst), ids = ldu4(out, PL_IDS, dst);
+        const uint4 hit = ldu4(out, PL_HIT, dst);
         const uint32_t flags = static_cast<uint32_t>(__double2hiint(p4.y));
+        double2 p0 = make_double2(0.0, 0.0), p1 = p0, p2 = p0;
+        if (flags & PENDING_CONNECT) { // planes 0 to 2 describe the connection
+            p0 = planes[dst];
+            p1 = planes[cap + dst];
+            p2 = planes[2 * cap + dst];
+        }
         PathVertex v{};
         v.point = v3(r0.x, r0.y, r1.x);
         v.color = v3(s1.y, cc.x, cc.y);
@@ -1006,6 +1023,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PASS ? PTK_BOUNCE_WAVES :
                 st2(out, PL_COL, dst, v.color.y, v.color.z);
             }
             stu4(out, PL_HIT, dst, static_cast<uint32_t>(__double2loint(nv.t)), static_cast<uint32_t>(__double2hiint(nv.t)), hit.z, hit.w);
+            const uint4 ids = ldu4(out, PL_IDS, dst); // (the counter of the random stream stays)
             stu4(out, PL_IDS, dst, ids.x, static_cast<uint32_t>(nv.obj), static_cast<uint32_t>(nv.prim), 0u);
             out.cls[dst] = static_cast<uint8_t>(nv.cls);
         }

@@ -479,7 +479,7 @@ int trace_batch(PtkScene* s, BatchLane& lane, const BatchParams& b) {
             timer.begin(3);
             launch_traverse(lc, bound, s->dev, lane.queues, lane.d_statistics + STATISTICS_SET);
             timer.end();
-            timer.begin(0);
+            timer.begin(2); // (not the k_bounce family: that one's time per launch is k_bounce's own)
             launch_bounce_resume(lc, bound, s->dev, b, next, lane.results, lane.d_statistics, lane.queues);
             launch_count_classes(lc, bound, pool_rounds, s->dev, next, info, lane.block_counts, lane.count_stride);
             timer.end();
@@ -491,7 +491,7 @@ int trace_batch(PtkScene* s, BatchLane& lane, const BatchParams& b) {
         launched++;
         st.bounce_launch_rounds++;
         st.bin_launches += 2;
-        st.bounce_launches += s->dev.has_meshes ? 2 : 1;
+        st.bounce_launches += 1;
     }
     unsigned long long* totals = lane.d_statistics + 2 * STATISTICS_SET;
     launch_sum_statistics(g_stream, lane.d_statistics, totals);
