@@ -637,7 +637,13 @@ int for_each_batch(PtkScene* s, const PtkRenderJob* job, F&& after_batch, uint32
             }
             if (other_rc != PTK_OK) other_message = g_error; // the message is the thread's own
         });
-        rc = run_lane(0);
+        try {
+            rc = run_lane(0);
+        }
+        catch (...) { // the worker is joined whatever happens here
+            worker.join();
+            throw;
+        }
         worker.join();
         if (rc == PTK_OK && other_rc != PTK_OK) rc = fail(other_rc, other_message);
         if (rc == PTK_OK) {
