@@ -437,3 +437,40 @@ def test_record_staging_through_lds_delivers_every_record():
     for n in (1, 255, 4096, 1 << 20):
         assert pt.device_lib().ptk_selftest_record_staging(n, C.byref(bad)) == 0, pt.device_lib().ptk_last_error()
         assert bad.value == 0, (n, bad.value)
+
+
+def test_tuning_knobs_reject_what_they_do_not_know():
+    for name, value in (("batch_lanes", 3), ("batch_lanes", -1), ("launch_ahead", 8), ("launch_ahead", -1), ("tail_records", -1),
+                        ("tail_records", (1 << 24) + 1), ("traverse_lanes", 2), ("gpu_bvh_build", 2), ("no_such_knob", 1)):
+        with pytest.raises(RuntimeError):
+            pt.set_option(name, value)
+    for name, value in (("batch_lanes", 0), ("launch_ahead", 7), ("tail_records", 1 << 20), ("traverse_lanes", 1), ("gpu_bvh_build", 0)):
+        pt.set_option(name, value)  # the defaults
+
+
+# Two batches in flight, each on a stream and a host thread of its own, at a size the oracle can follow: a job of 2^21
+# paths in a scene with a mesh, against the same job traced one batch at a time and against the oracle on a run of it.
+def test_two_batches_in_flight_give_the_same_samples(scene_dirs, ob):
+    hs = pt.load_scene_directory(scene_dirs["mesh_rough_glass"])
+    n = hs.settings.width * hs.settings.height
+    spp = (1 << 21) // n + 1
+    job = pt.make_job(0, n, spp, 0, 5)
+    pt.set_option("batch_lanes", 2)
+    try:
+        dev = pt.DeviceScene(hs)
+        two = dev.trace_samples(job)
+        two_stats = dev.stats()
+        pt.set_option("batch_lanes", 1)
+        dev = pt.DeviceScene(hs)
+        one = dev.trace_samples(job)
+        one_stats = dev.stats()
+    finally:
+        pt.set_option("batch_lanes", 0)
+    for a, b in zip(two, one):
+        assert np.array_equal(a, b)
+    for field in ("paths", "vertices", "extension_rays", "shadow_rays", "traversed_rays", "nodes_visited", "triangles_tested"):
+        assert getattr(two_stats, field) == getattr(one_stats, field), field
+    assert two_stats.paths == n * spp
+    small = pt.make_job(100, 64, 4, 0, 5)
+    got, want = pt.DeviceScene(hs).trace_samples(small), ob.OracleScene(hs).trace_samples(small)
+    assert np.isclose(got[0], want[0], rtol=1e-9, atol=1e-12).all(axis=-1).mean() >= 0.99
