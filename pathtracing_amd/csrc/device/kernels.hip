@@ -197,6 +197,9 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_WAVES) void 
     bool any_hit = false;
     int32_t node = BVH_EMPTY;   // BVH_EMPTY: the walk of the current mesh is over (or has not begun), or the lane has no ray
     int tri_i = 0;              // the triangle of the lane's leaf that is tested next
+#ifdef PTK_TRAVERSE_PROBE
+    uint32_t ray_steps = 0;
+#endif
     // A lane whose walk of a mesh is over (or has not begun) moves on to the ray's next mesh, or hands in the result.
     auto next_mesh = [&]() {
         if (has_ray && node == BVH_EMPTY) {
@@ -214,6 +217,12 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_WAVES) void 
             else {
                 queues.results[slot] = best;
                 has_ray = false;
+#ifdef PTK_TRAVERSE_PROBE
+                stat[4] += ray_steps > 128 ? 1 : 0; // rays by the number of passes they took
+                stat[5] += ray_steps > 512 ? 1 : 0;
+                stat[6] += ray_steps > 2048 ? 1 : 0;
+                ray_steps = 0;
+#endif
             }
         }
     };
@@ -259,6 +268,9 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_WAVES) void 
         stat[7] += has_ray ? 1 : 0;                      // lanes that held a ray in them
 #endif
         if (node != BVH_EMPTY) { // (a lane without a ray holds BVH_EMPTY too)
+#ifdef PTK_TRAVERSE_PROBE
+            ray_steps++;
+#endif
             const WalkStep step = walk_step<true>(sc, node, tri_i, first_tri, org, rp, slab, best.t, st);
             if (step.found) {
                 best.obj = object;

@@ -513,8 +513,9 @@ int trace_batch(PtkScene* s, BatchLane& lane, const BatchParams& b) {
     if (s->dev.has_meshes) { // k_traverse: ray request in, result out, the 112 bytes of a node that hold boxes and children, 72-byte triangle vertices
         const unsigned long long* t = lane.h_rays + N_STATISTICS;
 #ifdef PTK_TRAVERSE_PROBE
-        std::fprintf(stderr, "traverse probe: rays %llu, nodes %llu, triangles %llu, passes of a wave %llu, lanes with a ray in them %llu\n",
-                     t[0], t[1], t[2], t[3], t[7]);
+        std::fprintf(stderr, "traverse probe: rays %llu, nodes %llu, triangles %llu, passes of a wave %llu, lanes with a ray in them %llu, "
+                             "rays of more than 128 / 512 / 2048 passes %llu / %llu / %llu\n",
+                     t[0], t[1], t[2], t[3], t[7], t[4], t[5], t[6]);
 #endif
         const uint64_t tb = TRAVERSE_BYTES_PER_RAY * t[0] + NODE_BYTES * t[1] + sizeof(TriHot) * t[2];
         st.traversed_rays += t[0];
