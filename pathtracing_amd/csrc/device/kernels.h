@@ -32,7 +32,10 @@ struct LaunchContext {
 // has to wait for a count before it queues the next bounce.
 // block_counts: [N_CLASSES][count_stride] per-chunk class counts; count_stride >= chunk_capacity(capacity)
 void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathPool& pool, const SampleResults& res,
-                     BinInfo* first_info, uint32_t* block_counts, uint32_t count_stride);
+                     BinInfo* first_info, uint32_t* block_counts, uint32_t count_stride, const DeferQueues& queues);
+// scenes with meshes, after launch_generate and launch_traverse: completes the camera rays that were queued
+void launch_primary_resume(hipStream_t s, uint32_t n_paths, const DevScene& sc, const PathPool& pool, const SampleResults& res,
+                           const DeferQueues& queues);
 // scan + scatter: class-sorted index list of the records of `pool` from the counts its writer left, summary in *info
 void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_t bound, uint32_t rounds, const BinInfo* previous,
                 uint32_t* block_counts, uint32_t count_stride, BinInfo* info, uint32_t* list_out);

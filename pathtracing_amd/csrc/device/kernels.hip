@@ -123,6 +123,38 @@ __global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathPool pool, const BinI
         if (classes[r] >= 0) list_out[counts[r][wave][classes[r]] + below[r]] = first + r * BLOCK + threadIdx.x;
 }
 
+// Completes the records of the camera rays that waited for k_traverse: where the ray ends (the closest hit of the
+// object scan, overridden where a triangle is closer, or the free-flight distance k_generate left in the record),
+// and the class of that vertex; a ray that leaves the scene takes the background colour.
+__global__ __launch_bounds__(BLOCK) void k_primary_resume(DevScene sc, PathPool pool, SampleResults res, DeferQueues queues) {
+    const uint32_t n = queues.counters[1];
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const uint32_t sid = queues.vertices[i];
+        const RayResult found = queues.results[2 * sid + 1];
+        const uint4 hit = ldu4(pool, PL_HIT, sid), ids = ldu4(pool, PL_IDS, sid);
+        const double scatter_distance = __hiloint2double(static_cast<int>(hit.y), static_cast<int>(hit.x));
+        HitInfo h;
+        no_hit(h);
+        if (found.obj >= 0) {
+            const DevObject& o = sc.objects[found.obj];
+            h.t = found.t;
+            h.obj = found.obj;
+            h.prim = o.type == PTK_OBJ_MESH ? found.prim : (o.type == PTK_OBJ_TRIANGLE ? static_cast<int>(o.first_tri) : 0);
+            h.cls = o.mat.type;
+        }
+        const Vertex v = vertex_of(h, scatter_distance);
+        if (v.cls < 0) {
+            flush_color(res, sid, sc.background[0], sc.background[1], sc.background[2], false);
+            pool.cls[sid] = CLASS_DONE;
+        }
+        else {
+            stu4(pool, PL_HIT, sid, static_cast<uint32_t>(__double2loint(v.t)), static_cast<uint32_t>(__double2hiint(v.t)), hit.z, hit.w);
+            stu4(pool, PL_IDS, sid, ids.x, static_cast<uint32_t>(v.obj), static_cast<uint32_t>(v.prim), 0u);
+            pool.cls[sid] = static_cast<uint8_t>(v.cls);
+        }
+    }
+}
+
 // Counts, for every chunk of the list `info` describes, the classes of the records the bounce wrote for it:
 // block_counts[class][chunk], the input of the next class sort.  Scenes with meshes use it: there two kernels write
 // the records of a chunk (k_bounce, and k_bounce_resume for the vertices that waited for k_traverse), and counting
@@ -600,10 +632,11 @@ uint32_t chunk_capacity(uint32_t records) {
 }
 
 void launch_generate(hipStream_t s, const DevScene& sc, const BatchParams& b, const PathPool& pool, const SampleResults& res,
-                     BinInfo* first_info, uint32_t* block_counts, uint32_t count_stride) {
+                     BinInfo* first_info, uint32_t* block_counts, uint32_t count_stride, const DeferQueues& queues) {
     const dim3 grid(min(bin_blocks(b.n_paths), static_cast<uint32_t>(STATISTICS_SLOTS))), block(BLOCK);
-    if (sc.has_triangles) hipLaunchKernelGGL(k_generate<true>, grid, block, 0, s, sc, b, pool, res, first_info, block_counts, count_stride);
-    else hipLaunchKernelGGL(k_generate<false>, grid, block, 0, s, sc, b, pool, res, first_info, block_counts, count_stride);
+    if (sc.has_meshes) hipLaunchKernelGGL((k_generate<true, true>), grid, block, 0, s, sc, b, pool, res, first_info, block_counts, count_stride, queues);
+    else if (sc.has_triangles) hipLaunchKernelGGL((k_generate<true, false>), grid, block, 0, s, sc, b, pool, res, first_info, block_counts, count_stride, queues);
+    else hipLaunchKernelGGL((k_generate<false, false>), grid, block, 0, s, sc, b, pool, res, first_info, block_counts, count_stride, queues);
 }
 
 void launch_bin(hipStream_t s, const DevScene& sc, const PathPool& pool, uint32_t bound, uint32_t rounds, const BinInfo* previous,
@@ -708,6 +741,11 @@ void launch_bounce_resume(const LaunchContext& lc, uint32_t bound, const DevScen
     PTK_CASE(true, true, true);
     PTK_CASE(true, true, false);
 #undef PTK_CASE
+}
+
+void launch_primary_resume(hipStream_t s, uint32_t n_paths, const DevScene& sc, const PathPool& pool, const SampleResults& res,
+                           const DeferQueues& queues) {
+    hipLaunchKernelGGL(k_primary_resume, dim3(min((n_paths + BLOCK - 1) / BLOCK, 8192u)), dim3(BLOCK), 0, s, sc, pool, res, queues);
 }
 
 void launch_count_classes(const LaunchContext& lc, uint32_t bound, uint32_t rounds, const DevScene& sc, const PathPool& out, const BinInfo* info,

@@ -292,11 +292,16 @@ PTK_DEV void store_chunk_counts(uint32_t (*wave_counts)[N_CLASSES], const uint32
 // -------------------------------------------------------------------------------------------------
 // Camera samples and their first vertex.  The first pool holds the records in sample order as one
 // run (described to the class sort as class 0); chunk j = samples [j * BIN_CHUNK, (j + 1) * BIN_CHUNK).
-template<bool TRIS>
+// DEFER (scenes with meshes): a camera ray that enters the bounds of a mesh is queued for k_traverse like the rays of
+// a bounce, its record written with the free-flight distance where the distance to the first vertex belongs;
+// k_primary_resume completes it and k_count_classes counts the classes of the chunks.
+template<bool TRIS, bool DEFER>
 __global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, PathPool pool, SampleResults res, BinInfo* first_info,
-                                                    uint32_t* block_counts, uint32_t count_stride) {
-    __shared__ StackEntry lds_stack[TRIS ? LDS_STACK_DEPTH * BLOCK : 1];
+                                                    uint32_t* block_counts, uint32_t count_stride, DeferQueues queues) {
+    __shared__ StackEntry lds_stack[TRIS && !DEFER ? LDS_STACK_DEPTH * BLOCK : 1];
     __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
+    __shared__ uint32_t queue_counts[BLOCK / 64];
+    __shared__ uint32_t queue_base;
     PTK_TRAVERSAL_STACK(st, lds_stack, sc);
     if (blockIdx.x == 0 && threadIdx.x < N_CLASSES) {
         first_info->start[threadIdx.x] = threadIdx.x == 0 ? 0u : b.n_paths;
@@ -311,14 +316,30 @@ __global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, 
         for (int r = 0; r < BIN_ROUNDS; r++) {
             const uint32_t sid = chunk * BIN_CHUNK + r * BLOCK + threadIdx.x;
             int cls = -1;
+            bool deferred = false;
+            RayState rays[1];
+            V3 org = v3(0.0), dir = v3(0.0);
             if (sid < b.n_paths) {
                 uint32_t pixel, sample;
                 sample_coordinates(b, sid, pixel, sample);
                 Rng rng{rng_key(b.seed, pixel, sample), 0};
-                V3 org, dir;
                 camera_ray(sc, pixel, rng, org, dir);
                 const uint32_t medium = static_cast<uint32_t>(sc.background_medium) & 0xFFFFu;
-                const Vertex v = next_vertex<TRIS>(sc, b, org, dir, medium, sid, rng.ctr, st);
+                Vertex v;
+                if (DEFER) {
+                    const double scatter_distance = free_flight_distance(sc, b, medium, sid, rng.ctr);
+                    rays[0] = ray_state<TRIS>(org, dir, scatter_distance);
+                    scan_objects<TRIS, MESH_DEFER, 1>(sc, org, rays, st);
+                    deferred = rays[0].needs_mesh;
+                    v = vertex_of(hit_of(sc, rays[0]), scatter_distance);
+                    if (deferred) { // where the ray ends is not known yet
+                        v.t = scatter_distance;
+                        v.obj = -1;
+                        v.prim = 0;
+                        v.cls = 0;
+                    }
+                }
+                else v = next_vertex<TRIS>(sc, b, org, dir, medium, sid, rng.ctr, st);
                 cls = v.cls;
                 if (v.cls < 0) { // color = throughput (1) * background_color
                     flush_color(res, sid, sc.background[0], sc.background[1], sc.background[2], false);
@@ -336,14 +357,37 @@ __global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, 
                     stu4(pool, PL_HIT, sid, static_cast<uint32_t>(__double2loint(v.t)), static_cast<uint32_t>(__double2hiint(v.t)),
                          0u | (RAY_TRANSMITTED << TYPE_SHIFT) | (medium << 16), sid);
                     stu4(pool, PL_IDS, sid, rng.ctr, static_cast<uint32_t>(v.obj), static_cast<uint32_t>(v.prim), 0u);
-                    pool.cls[sid] = static_cast<uint8_t>(v.cls);
+                    if (!deferred) pool.cls[sid] = static_cast<uint8_t>(v.cls);
                 }
             }
+            if (DEFER) { // queue the deferred camera rays of this round: one atomic per block (one ray per vertex)
+                const unsigned long long mask = __ballot(deferred);
+                const int wave = threadIdx.x >> 6;
+                if ((threadIdx.x & 63) == 0) queue_counts[wave] = static_cast<uint32_t>(__popcll(mask));
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    unsigned long long total = 0;
+                    for (int w = 0; w < BLOCK / 64; w++) total += queue_counts[w];
+                    const unsigned long long before =
+                        total ? atomicAdd(reinterpret_cast<unsigned long long*>(queues.counters), total | (total << 32)) : 0ull;
+                    queue_base = static_cast<uint32_t>(before); // rays and vertices advance together
+                }
+                __syncthreads();
+                if (deferred) {
+                    uint32_t slot = queue_base + lanes_below(mask);
+                    for (int w = 0; w < wave; w++) slot += queue_counts[w];
+                    queues.vertices[slot] = sid;
+                    queues.rays[slot] = RayRequest{org.x, org.y, org.z, dir.x, dir.y, dir.z, rays[0].limit, 2 * sid + 1, static_cast<uint32_t>(rays[0].obj)};
+                }
+                __syncthreads(); // queue_counts and queue_base are rewritten next round
+            }
+            else {
 #pragma unroll
-            for (int c = 0; c < N_CLASSES; c++)
-                if ((sc.class_mask >> c) & 1u) my_counts[c] += static_cast<uint32_t>(__popcll(__ballot(cls == c)));
+                for (int c = 0; c < N_CLASSES; c++)
+                    if ((sc.class_mask >> c) & 1u) my_counts[c] += static_cast<uint32_t>(__popcll(__ballot(cls == c)));
+            }
         }
-        store_chunk_counts(wave_counts, my_counts, block_counts, count_stride, chunk);
+        if (!DEFER) store_chunk_counts(wave_counts, my_counts, block_counts, count_stride, chunk);
     }
 }
 

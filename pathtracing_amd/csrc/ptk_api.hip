@@ -406,9 +406,20 @@ int trace_batch(PtkScene* s, BatchLane& lane, const BatchParams& b) {
     const uint32_t tail_records = g_tail_records.load();
     const int launch_ahead = g_launch_ahead.load();
     HIP_TRY(hipMemsetAsync(lane.d_statistics, 0, STATISTICS_BYTES, g_stream));
+    if (s->dev.has_meshes) HIP_TRY(hipMemsetAsync(lane.queues.counters, 0, 4 * sizeof(uint32_t), g_stream));
     timer.begin(2);
-    launch_generate(g_stream, s->dev, b, lane.pools[0], lane.results, &lane.d_info[1], lane.block_counts, lane.count_stride);
+    launch_generate(g_stream, s->dev, b, lane.pools[0], lane.results, &lane.d_info[1], lane.block_counts, lane.count_stride, lane.queues);
     timer.end();
+    if (s->dev.has_meshes) { // the camera rays that enter the bounds of a mesh: walk, complete, count the classes
+        timer.begin(3);
+        launch_traverse(lc, b.n_paths, s->dev, lane.queues, lane.d_statistics + STATISTICS_SET);
+        timer.end();
+        timer.begin(2);
+        launch_primary_resume(g_stream, b.n_paths, s->dev, lane.pools[0], lane.results, lane.queues);
+        launch_count_classes(lc, b.n_paths, BIN_ROUNDS, s->dev, lane.pools[0], &lane.d_info[1], lane.block_counts, lane.count_stride);
+        timer.end();
+        st.traverse_launches++;
+    }
     st.paths += b.n_paths;
     st.algorithmic_bytes += GENERATE_BYTES_PER_PATH * b.n_paths;
 
