@@ -662,6 +662,7 @@ int for_each_batch(PtkScene* s, const PtkRenderJob* job, F&& after_batch, uint32
             HIP_TRY(hipEventRecord(other.fence, other.stream));
             HIP_TRY(hipStreamWaitEvent(s->ctx->stream, other.fence, 0));
         }
+        else (void) hipStreamSynchronize(other.stream); // nothing of the failed job is left running on the caller's buffers
     }
     for (int l = 0; l < n_lanes; l++) {
         add_stats(s->stats, s->lanes[l].stats);
