@@ -431,11 +431,16 @@ struct HitInfo {
 
 // One object's DevShape through the constant address space: the index is wave-uniform, so the
 // record arrives in SGPRs by scalar loads instead of costing vector loads and registers per lane.
+PTK_DEV void load_unit(const PTK_CONSTANT ShapeUnit* p, ShapeUnit& s) {
+#pragma unroll
+    for (int k = 0; k < 7; k++) s.f[k] = p->f[k];
+    s.index = p->index;
+}
 PTK_DEV void load_shape(const PTK_CONSTANT DevShape* p, DevShape& s) {
 #pragma unroll
     for (int k = 0; k < 14; k++) s.f[k] = p->f[k];
     s.type = p->type;
-    s.cls = p->cls;
+    s.index = p->index;
     s.first_tri = p->first_tri;
     s.bvh_root = p->bvh_root;
 }
@@ -453,6 +458,7 @@ struct RayState {
     // hit the smallest double above the ray's t_max (the reference takes d <= t_max for the first hit and
     // d < closest afterwards).
     double limit;
+    V3 inv;          // frcp of the direction's components, when the scene has axis-aligned rectangles (else unused)
     int obj, prim;   // closest hit so far: object (-1: none) and triangle (leaf order; 0 for other shapes)
     bool needs_mesh; // MESH_DEFER: the ray enters the bounds of some mesh before its limit
 };
@@ -492,19 +498,60 @@ PTK_DEV double next_above(double t) {
     return __longlong_as_double(t > 0 ? bits + 1 : bits - 1);
 }
 
-template<bool TRIS, int MODE, int N>
-PTK_DEV void test_shape(const DevScene& sc, const DevShape& o, int index, const V3& org, RayState (&rays)[N], TraversalStack& st) {
-    if (o.type == PTK_OBJ_SPHERE) { // :106-119
-        V3 c = v3(o.f[0], o.f[1], o.f[2]);
-        double cc = len2(c - org) - o.f[3] * o.f[3];
+// A rectangle whose normal is coordinate axis K and whose sides run along the other two (ShapeUnit of the run of
+// axis K).  The general test (test_shape) gives the same bits for such a rectangle: its dot products with a unit axis
+// pick one coordinate exactly, whatever the axis's sign, and fdiv(s n, -(d n)) == -fdiv(s, d) for n = +-1.  What is
+// saved: the dot products, and the reciprocal of the division, which all rectangles of one axis share (RayState::inv).
+template<int K, int N>
+PTK_DEV void test_axis_rectangle(const ShapeUnit& o, const V3& org, RayState (&rays)[N]) {
+    constexpr int J = (K + 1) % 3, M = (K + 2) % 3;
+    const double sk = axis<K>(org) - o.f[0], sj = axis<J>(org) - o.f[1], sm = axis<M>(org) - o.f[2];
 #pragma unroll
-        for (int k = 0; k < N; k++) {
-            double d;
-            double b = 2 * (rays[k].dir_dot_org - dot(rays[k].dir, c));
-            bool success = solve_quadratic_select(b, cc, d);
-            accept_hit(rays[k], success, d, index, 0);
-        }
+    for (int k = 0; k < N; k++) {
+        const double dk = axis<K>(rays[k].dir);
+        const double d = -fdiv_by(sk, dk, axis<K>(rays[k].inv));
+        const bool outside = fabs(fma(axis<J>(rays[k].dir), d, sj)) > o.f[3] || fabs(fma(axis<M>(rays[k].dir), d, sm)) > o.f[4];
+        accept_hit(rays[k], !(fabs(dk) < EPSILON) && !outside, d, o.index, 0);
     }
+}
+
+// Sphere::find_closest_object_hit (src/objects.cpp:106-119); f: centre and radius.
+template<int N>
+PTK_DEV void test_sphere(const double* f, int index, const V3& org, RayState (&rays)[N]) {
+    V3 c = v3(f[0], f[1], f[2]);
+    double cc = len2(c - org) - f[3] * f[3];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        double d;
+        double b = 2 * (rays[k].dir_dot_org - dot(rays[k].dir, c));
+        bool success = solve_quadratic_select(b, cc, d);
+        accept_hit(rays[k], success, d, index, 0);
+    }
+}
+
+// One run of ShapeUnits: KIND 0, 1, 2 rectangles along that axis, 3 spheres.  The record of unit i + 1 is requested
+// before unit i is tested, so the scalar-load latency overlaps the arithmetic.
+template<int KIND, int N>
+PTK_DEV void scan_units(const PTK_CONSTANT ShapeUnit* units, int n, const V3& org, RayState (&rays)[N]) {
+    if (n <= 0) return;
+    ShapeUnit o;
+    load_unit(units, o);
+    // The first record must have arrived before the loop is entered: a load still pending at the loop header makes
+    // the compiler wait at the top of every iteration, which also waits for the prefetch issued there.
+    asm volatile("" : : "s"(o.index));
+    for (int i = 0; i < n; i++) {
+        ShapeUnit next;
+        load_unit(units + (i + 1 < n ? i + 1 : i), next);
+        if (KIND == 3) test_sphere<N>(o.f, o.index, org, rays);
+        else test_axis_rectangle<KIND, N>(o, org, rays);
+        o = next;
+    }
+}
+
+template<bool TRIS, int MODE, int N>
+PTK_DEV void test_shape(const DevScene& sc, const DevShape& o, const V3& org, RayState (&rays)[N], TraversalStack& st) {
+    const int index = o.index;
+    if (o.type == PTK_OBJ_SPHERE) test_sphere<N>(o.f, index, org, rays);
     else if (o.type == PTK_OBJ_PLANE || o.type == PTK_OBJ_RECTANGLE) { // :185-211, :237-255
         V3 nrm = v3(o.f[3], o.f[4], o.f[5]);
         V3 shifted = org - v3(o.f[0], o.f[1], o.f[2]);
@@ -520,7 +567,7 @@ PTK_DEV void test_shape(const DevScene& sc, const DevShape& o, int index, const 
         if (o.type == PTK_OBJ_RECTANGLE) {
             V3 a1 = v3(o.f[6], o.f[7], o.f[8]), a2 = v3(o.f[9], o.f[10], o.f[11]);
             double s1 = dot(shifted, a1), s2 = dot(shifted, a2);
-            double half1 = o.f[12] / 2.0 + EPSILON, half2 = o.f[13] / 2.0 + EPSILON;
+            double half1 = o.f[12], half2 = o.f[13]; // L / 2 + EPSILON
 #pragma unroll
             for (int k = 0; k < N; k++) {
                 bool outside = fabs(fma(dot(rays[k].dir, a1), d[k], s1)) > half1 || fabs(fma(dot(rays[k].dir, a2), d[k], s2)) > half2;
@@ -571,26 +618,36 @@ PTK_DEV void no_hit(HitInfo& hit) {
 // scenes made of spheres, planes and rectangles only.
 template<bool TRIS, int MODE, int N>
 PTK_DEV void scan_objects(const DevScene& sc, const V3& org, RayState (&rays)[N], TraversalStack& st) {
-    const PTK_CONSTANT DevShape* shapes = (const PTK_CONSTANT DevShape*) sc.shapes;
-    const int n = sc.n_objects;
+    const PTK_CONSTANT ScanHeader* header = (const PTK_CONSTANT ScanHeader*) sc.scan;
+    const PTK_CONSTANT ShapeUnit* units = (const PTK_CONSTANT ShapeUnit*) (header + 1);
+    const int n_x = header->n_axis[0], n_y = header->n_axis[1], n_z = header->n_axis[2], n_spheres = header->n_spheres;
+    scan_units<0, N>(units, n_x, org, rays);
+    units += n_x;
+    scan_units<1, N>(units, n_y, org, rays);
+    units += n_y;
+    scan_units<2, N>(units, n_z, org, rays);
+    units += n_z;
+    scan_units<3, N>(units, n_spheres, org, rays);
+    const PTK_CONSTANT DevShape* shapes = (const PTK_CONSTANT DevShape*) (units + n_spheres);
+    const int n = header->n_others;
+    if (n <= 0) return;
     DevShape o;
-    if (n > 0) load_shape(shapes, o);
-    // The first record must have arrived before the loop is entered: a load still pending at the
-    // loop header makes the compiler wait at the top of every iteration, which also waits for the
-    // prefetch of the next record issued there.
-    asm volatile("" : : "s"(o.type));
+    load_shape(shapes, o);
+    asm volatile("" : : "s"(o.type)); // (as in scan_units)
     for (int i = 0; i < n; i++) {
         DevShape next;
         load_shape(shapes + (i + 1 < n ? i + 1 : i), next);
-        test_shape<TRIS, MODE, N>(sc, o, i, org, rays, st);
+        test_shape<TRIS, MODE, N>(sc, o, org, rays, st);
         o = next;
     }
 }
 
 template<bool TRIS>
-PTK_DEV RayState ray_state(const V3& org, const V3& dir, double t_max) {
+PTK_DEV RayState ray_state(const DevScene& sc, const V3& org, const V3& dir, double t_max) {
     RayState r;
     r.dir = dir;
+    r.inv = v3(0.0);
+    if (sc.has_axis_rectangles) r.inv = v3(frcp(dir.x), frcp(dir.y), frcp(dir.z));
     r.dir_dot_org = dot(dir, org);
     r.rp = RayPrep{};
     if (TRIS) r.rp = prepare_ray(dir);
@@ -616,7 +673,7 @@ PTK_DEV HitInfo hit_of(const DevScene& sc, const RayState& r) {
 
 template<bool TRIS>
 PTK_DEV bool closest_hit(const DevScene& sc, const V3& org, const V3& dir, double t_max, HitInfo& hit, TraversalStack& st) {
-    RayState rays[1] = {ray_state<TRIS>(org, dir, t_max)};
+    RayState rays[1] = {ray_state<TRIS>(sc, org, dir, t_max)};
     scan_objects<TRIS, MESH_INLINE, 1>(sc, org, rays, st);
     hit = hit_of(sc, rays[0]);
     return hit.obj >= 0;

@@ -171,7 +171,7 @@ PTK_DEV void load_surface(const SampleResults& res, size_t sid, const double2& c
 // Statistics without atomics on shared lines: every block adds its totals to its own slot.
 // values: [0] visibility-march segments, [1] extension rays, [2] connections marched,
 // [3] records written for the next bounce, [4] vertices shaded by k_tail after its first round,
-// [5] unused, [6] and [7] cycle stamps of the sections of k_bounce in the -DPTK_STAMPS build.
+// [5], [6] and [7] cycle stamps of the sections of k_bounce in the -DPTK_STAMPS build (else unused).
 PTK_DEV void add_block_statistics(unsigned long long* slots, uint32_t (*wave_sums)[N_STATISTICS], uint32_t* mine) {
 #pragma unroll
     for (int k = 0; k < N_STATISTICS; k++)
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, 
                 Vertex v;
                 if (DEFER) {
                     const double scatter_distance = free_flight_distance(sc, b, medium, sid, rng.ctr);
-                    rays[0] = ray_state<TRIS>(org, dir, scatter_distance);
+                    rays[0] = ray_state<TRIS>(sc, org, dir, scatter_distance);
                     scan_objects<TRIS, MESH_DEFER, 1>(sc, org, rays, st);
                     deferred = rays[0].needs_mesh;
                     v = vertex_of(hit_of(sc, rays[0]), scatter_distance);
@@ -644,9 +644,9 @@ PTK_DEV uint32_t medium_bits_of(const PathVertex& v) {
 // The two rays that leave a shaded vertex: [0] the shadow ray of the connection, [1] the extension
 // ray up to its free-flight distance.  A ray that is not wanted gets t_max = -infinity.
 template<bool TRIS>
-PTK_DEV void vertex_rays(const PathVertex& v, bool alive, double scatter_distance, RayState (&rays)[2]) {
-    rays[0] = ray_state<TRIS>(v.point, v.sh_dir, v.connect ? INF : -INF);
-    rays[1] = ray_state<TRIS>(v.point, v.n_dir, alive ? scatter_distance : -INF);
+PTK_DEV void vertex_rays(const DevScene& sc, const PathVertex& v, bool alive, double scatter_distance, RayState (&rays)[2]) {
+    rays[0] = ray_state<TRIS>(sc, v.point, v.sh_dir, v.connect ? INF : -INF);
+    rays[1] = ray_state<TRIS>(sc, v.point, v.n_dir, alive ? scatter_distance : -INF);
 }
 
 // The rest of the vertex once the closest hits of its two rays are known: the visibility march
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
 #define PTK_STAMP(k)                                                                                   \
     {                                                                                                  \
         const uint64_t now_ = __builtin_readcyclecounter();                                            \
-        if ((threadIdx.x & 63) == 0) stat[6 + (k)] += static_cast<uint32_t>((now_ - stamp_) >> 4);     \
+        if ((threadIdx.x & 63) == 0) stat[(k) == 2 ? 5 : 6 + (k)] += static_cast<uint32_t>((now_ - stamp_) >> 4); \
         stamp_ = now_;                                                                                 \
     }
     uint64_t stamp_ = __builtin_readcyclecounter();
@@ -857,13 +857,14 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
                 // the shadow ray of the connection and the extension ray leave the vertex together
                 double scatter_distance = INF;
                 if (alive) scatter_distance = free_flight_distance(sc, b, medium_bits_of(v), v.sid, v.rng.ctr);
-                vertex_rays<TRIS>(v, alive, scatter_distance, rays);
+                vertex_rays<TRIS>(sc, v, alive, scatter_distance, rays);
                 scan_objects<TRIS, DEFER ? MESH_DEFER : MESH_INLINE, 2>(sc, v.point, rays, st);
+                PTK_STAMP(1)
                 deferred = DEFER && (rays[0].needs_mesh || rays[1].needs_mesh);
                 origin = v.point;
                 if (!deferred) new_cls = finish_vertex<TRIS, UV, PASS>(sc, out, res, dst, v, alive, scatter_distance, hit_of(sc, rays[0]), hit_of(sc, rays[1]), st, stat);
                 else store_pending(out, queues, dst, v, alive, scatter_distance);
-                PTK_STAMP(1)
+                PTK_STAMP(2)
             }
             if (DEFER) { // queue the deferred vertices of this round and their rays: one atomic per block
                 const uint32_t my_rays = deferred ? (rays[0].needs_mesh ? 1u : 0u) + (rays[1].needs_mesh ? 1u : 0u) : 0u;
@@ -983,7 +984,7 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
             double scatter_distance = INF;
             if (alive) scatter_distance = free_flight_distance(sc, b, medium_bits_of(v), v.sid, v.rng.ctr);
             RayState rays[2];
-            vertex_rays<TRIS>(v, alive, scatter_distance, rays);
+            vertex_rays<TRIS>(sc, v, alive, scatter_distance, rays);
             scan_objects<TRIS, MESH_INLINE, 2>(sc, v.point, rays, st);
             cls = finish_vertex<TRIS, UV, PASS>(sc, out, res, i, v, alive, scatter_distance, hit_of(sc, rays[0]), hit_of(sc, rays[1]), st, stat);
             __threadfence(); // the record written above is read back by the next round

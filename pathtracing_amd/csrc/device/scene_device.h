@@ -70,16 +70,41 @@ struct DevObject {
 };
 static_assert(sizeof(DevObject) == 328, "the LDS copies of the object table rely on this stride");
 
-// What the closest-hit loop reads per object: 128 bytes fetched by two scalar loads.
+// What the closest-hit loop (scan_objects, geometry.h) reads.  DevScene::scan points at a ScanHeader followed by the
+// scene's objects in the order the loop takes them:
+//   ShapeUnit[n_axis[0]]   rectangles whose normal is the x axis and whose sides run along y and z (up to sign):
+//                          f[0..2] the rectangle's point, coordinates k, k + 1, k + 2 (cyclic; k the normal's axis),
+//                          f[3], f[4] half sides + EPSILON along k + 1 and k + 2
+//   ShapeUnit[n_axis[1]], ShapeUnit[n_axis[2]]   the same for y and z
+//   ShapeUnit[n_spheres]   f[0..2] centre, f[3] radius
+//   DevShape[n_others]     everything else in table order, meshes last (or every object in table order: ordered_scan)
+// One type per loop: no dispatch on the type inside the loops, and 64 bytes (one scalar load) per object where that
+// is enough.  The reference scans the objects in table order and the first one wins an exact tie; here the order is
+// kept within each of the five runs, and between runs the earlier run wins.  Scenes in which that could matter
+// (two flat objects in one plane that would fall into different runs) keep every object in the last run.
+struct ShapeUnit { // 64 bytes
+    double f[7];
+    int32_t index; // the object's place in the scene's object table
+    int32_t _pad;
+};
+struct ScanHeader { // 64 bytes
+    int32_t n_axis[3];
+    int32_t n_spheres;
+    int32_t n_others;
+    int32_t _pad[11];
+};
+static_assert(sizeof(ShapeUnit) == 64 && sizeof(ScanHeader) == 64, "the scan's records are read by 64-byte scalar loads");
+// One object of the last run: 128 bytes fetched by two scalar loads.
 //   sphere            f[0..2] centre, f[3] radius
-//   plane, rectangle  f[0..2] point, f[3..5] normal, f[6..8] axis 1, f[9..11] axis 2, f[12] L1, f[13] L2
+//   plane, rectangle  f[0..2] point, f[3..5] normal, f[6..8] axis 1, f[9..11] axis 2, f[12] L1 / 2 + EPSILON, f[13] the
+//                     same of L2
 //   triangle          first_tri
 //   mesh              first_tri, bvh_root, f[0..5] bounds of the whole mesh (lo xyz, hi xyz),
 //                     f[6] != 0: no connection to a light passes through this mesh
 struct DevShape {
     double f[14];
     int32_t type;      // PTK_OBJ_*
-    int32_t cls;       // class (material type) of the object's material
+    int32_t index;     // the object's place in the scene's object table
     int32_t first_tri; // triangle: its index; mesh: first triangle of its range
     int32_t bvh_root;  // mesh: root node, -1 if empty
 };
@@ -151,13 +176,15 @@ struct DevScene {
     int32_t needs_uv; // some material reads a map larger than 1x1
     int32_t has_pass_through;    // some material can let a connection to a light through (allow_direct_light)
     int32_t tables_fit_lds;      // objects + light_objects + media take at most LDS_SCENE_DOUBLES doubles
+    int32_t has_axis_rectangles; // ScanHeader::n_axis is not all zero: rays carry the reciprocals of their direction
+    int32_t _pad0;
     int32_t width, height;
     int32_t max_depth, min_depth, nee, aa;
     int32_t background_medium, background_is_black;
     double background[3];
     DevCamera cam;
     const DevObject* objects;
-    const DevShape* shapes;      // one per object, same order
+    const ScanHeader* scan;      // the tables of the closest-hit loop (see ScanHeader)
     const DevMaterial* materials;
     const DevMedium* media;
     const DevMap* maps;

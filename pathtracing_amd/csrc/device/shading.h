@@ -58,9 +58,9 @@ PTK_DEV double specular_pdf(const DevScene& sc, const DevMaterial& m, const Surf
 
 template<int T>
 PTK_DEV double material_pdf(const DevScene& sc, const DevMaterial& m, const Surface& s, const V3& outgoing) { // brdf_pdf
-    if (T == PTK_MAT_DIFFUSE) return fmax(dot(outgoing, s.normal), 0.0) / PI; // :103-106
+    if (T == PTK_MAT_DIFFUSE) return div_pi(fmax(dot(outgoing, s.normal), 0.0)); // :103-106
     if (T == PTK_MAT_GLOSSY)                                                 // :316-320
-        return 0.5 * (fmax(dot(s.normal, outgoing) / PI, 0.0) + specular_pdf(sc, m, s, outgoing));
+        return 0.5 * (fmax(div_pi(dot(s.normal, outgoing)), 0.0) + specular_pdf(sc, m, s, outgoing));
     if (T == PTK_MAT_METALLIC_MICROFACET || T == PTK_MAT_REFLECTIVE_MICROFACET) return specular_pdf(sc, m, s, outgoing);
     return 0.0;
 }
@@ -79,7 +79,8 @@ template<int T>
 PTK_DEV V3 material_eval(const DevScene& sc, const DevMaterial& m, const Surface& s, const V3& outgoing, Rng& rng) {
     if (T == PTK_MAT_DIFFUSE) { // :83-88
         if (sample_transparency(sc, m, s, rng)) return v3(0.0);
-        return material_albedo(sc, m, s) / PI;
+        const V3 albedo = material_albedo(sc, m, s);
+        return v3(div_pi(albedo.x), div_pi(albedo.y), div_pi(albedo.z));
     }
     if (T == PTK_MAT_GLOSSY) { // :249-286
         if (sample_transparency(sc, m, s, rng)) return v3(0.0);

@@ -63,6 +63,9 @@ std::atomic<int> g_batch_lanes{0};
 std::atomic<bool> g_specialised{true};
 std::atomic<bool> g_quad_traverse{false};
 std::atomic<bool> g_gpu_bvh_build{false};
+// The closest-hit loop takes spheres and rectangles along the coordinate axes in runs of their own (option scan_runs,
+// read when a scene is created; 0: every object in table order through the general loop).
+std::atomic<bool> g_scan_runs{true};
 
 int fail(int code, const std::string& message) {
     g_error = message;
@@ -118,6 +121,20 @@ H3 hcross(H3 a, H3 b) { return H3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, 
 H3 hnormalize(H3 a) {
     double l = std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
     return H3{a.x / l, a.y / l, a.z / l};
+}
+// The coordinate axis a vector is a unit vector of, up to sign (every other component a zero of either sign); -1 for
+// any other vector.
+int unit_axis(double x, double y, double z) {
+    const double v[3] = {x, y, z};
+    int axis = -1;
+    for (int k = 0; k < 3; k++) {
+        if (std::fabs(v[k]) == 1.0) {
+            if (axis >= 0) return -1;
+            axis = k;
+        }
+        else if (v[k] != 0.0) return -1;
+    }
+    return axis;
 }
 void put(double* dst, H3 v) {
     dst[0] = v.x;
@@ -518,8 +535,8 @@ int trace_batch(PtkScene* s, BatchLane& lane, const BatchParams& b) {
                                   BOUNCE_BYTES_PER_CONTINUED * continued + BOUNCE_BYTES_PER_ENDED * (sum_vertices - continued);
     for (int c = 0; c < N_CLASSES; c++) st.class_vertices[c] += class_vertices[c];
 #ifdef PTK_STAMPS
-    std::fprintf(stderr, "wave-cycles/16: shade %llu, rays %llu; vertices %llu, rays %llu\n", lane.h_rays[6], lane.h_rays[7],
-                 (unsigned long long) sum_vertices, (unsigned long long) (segments + extensions));
+    std::fprintf(stderr, "wave-cycles/16: shade %llu, object scan %llu, finish %llu; vertices %llu, rays %llu\n", lane.h_rays[6], lane.h_rays[7],
+                 lane.h_rays[5], (unsigned long long) sum_vertices, (unsigned long long) (segments + extensions));
 #endif
     if (s->dev.has_meshes) { // k_traverse: ray request in, result out, the 112 bytes of a node that hold boxes and children, 72-byte triangle vertices
         const unsigned long long* t = lane.h_rays + N_STATISTICS;
@@ -731,6 +748,11 @@ int ptk_set_option(const char* name, int64_t value) {
     if (name && std::strcmp(name, "gpu_bvh_build") == 0) {
         if (value != 0 && value != 1) return fail(PTK_ERR_INVALID, "ptk_set_option: gpu_bvh_build must be 0 or 1");
         g_gpu_bvh_build = value != 0;
+        return PTK_OK;
+    }
+    if (name && std::strcmp(name, "scan_runs") == 0) { // read when a scene is created
+        if (value != 0 && value != 1) return fail(PTK_ERR_INVALID, "ptk_set_option: scan_runs must be 0 or 1");
+        g_scan_runs = value != 0;
         return PTK_OK;
     }
     if (name && std::strcmp(name, "traverse_lanes") == 0) {
@@ -1082,7 +1104,7 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
         DevShape& sh = shapes[i];
         std::memset(&sh, 0, sizeof(sh));
         sh.type = o.type;
-        sh.cls = materials[static_cast<size_t>(o.material)].type;
+        sh.index = static_cast<int32_t>(i);
         sh.first_tri = static_cast<int32_t>(o.first_tri);
         sh.bvh_root = o.bvh_root;
         if (o.type == PTK_OBJ_SPHERE) {
@@ -1114,9 +1136,74 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
             sh.f[6] = (!lets_light_through(m) && !m.is_light && !has_mesh_light) ? 1.0 : 0.0;
         }
         else if (o.type == PTK_OBJ_PLANE || o.type == PTK_OBJ_RECTANGLE) {
-            const double v[14] = {o.px, o.py, o.pz, o.nx, o.ny, o.nz, o.v1x, o.v1y, o.v1z, o.v2x, o.v2y, o.v2z, o.L1, o.L2};
+            // (the half sides with the test's slack: the same two IEEE operations the test would perform)
+            const double v[14] = {o.px, o.py, o.pz, o.nx, o.ny, o.nz, o.v1x, o.v1y, o.v1z, o.v2x, o.v2y, o.v2z, o.L1 / 2.0 + EPSILON,
+                                  o.L2 / 2.0 + EPSILON};
             std::memcpy(sh.f, v, sizeof(v));
         }
+    }
+    // The tables of the closest-hit loop (ScanHeader in scene_device.h): runs of one type each, so that the loop
+    // over a run has no dispatch on the type and reads 64 bytes per object.  The first object of the table wins an
+    // exact tie in the reference; the order is kept within a run and the earlier run wins between runs, so a
+    // rectangle along the axes stays out of its run (and is tested in table order with the rest) when a plane or
+    // rectangle of another kind lies in its plane: those are the objects that can tie with it bit for bit.
+    ScanHeader scan_header{};
+    std::vector<ShapeUnit> units[4]; // axis x, y, z; spheres
+    std::vector<DevShape> others;
+    {
+        struct AxisPlane {
+            int axis;
+            double at;
+        };
+        auto axis_rectangle = [&](const DevObject& o, int& kn, int& k1) {
+            kn = unit_axis(o.nx, o.ny, o.nz);
+            k1 = unit_axis(o.v1x, o.v1y, o.v1z);
+            const int k2 = unit_axis(o.v2x, o.v2y, o.v2z);
+            return o.type == PTK_OBJ_RECTANGLE && kn >= 0 && k1 >= 0 && k2 >= 0 && kn != k1 && kn != k2 && k1 != k2;
+        };
+        const bool runs = g_scan_runs.load();
+        std::vector<AxisPlane> taken; // planes along the axes that hold a plane or a rectangle of another kind
+        for (const DevObject& o : objects) {
+            int kn, k1;
+            if ((o.type == PTK_OBJ_PLANE || o.type == PTK_OBJ_RECTANGLE) && !axis_rectangle(o, kn, k1) && kn >= 0) {
+                const double p[3] = {o.px, o.py, o.pz};
+                taken.push_back(AxisPlane{kn, p[kn]});
+            }
+        }
+        std::vector<DevShape> meshes;
+        for (size_t i = 0; i < objects.size(); i++) {
+            const DevObject& o = objects[i];
+            int kn = -1, k1 = -1;
+            ShapeUnit unit{};
+            unit.index = static_cast<int32_t>(i);
+            if (runs && o.type == PTK_OBJ_SPHERE) {
+                std::memcpy(unit.f, shapes[i].f, 4 * sizeof(double));
+                units[3].push_back(unit);
+            }
+            else if (runs && axis_rectangle(o, kn, k1)) {
+                const double p[3] = {o.px, o.py, o.pz};
+                bool shared = false;
+                for (const AxisPlane& plane : taken) shared = shared || (plane.axis == kn && plane.at == p[kn]);
+                if (shared) {
+                    others.push_back(shapes[i]);
+                    continue;
+                }
+                const int j = (kn + 1) % 3, m = (kn + 2) % 3;
+                unit.f[0] = p[kn];
+                unit.f[1] = p[j];
+                unit.f[2] = p[m];
+                unit.f[3] = (k1 == j ? o.L1 : o.L2) / 2.0 + EPSILON;
+                unit.f[4] = (k1 == j ? o.L2 : o.L1) / 2.0 + EPSILON;
+                units[kn].push_back(unit);
+                dev.has_axis_rectangles = 1;
+            }
+            else if (runs && o.type == PTK_OBJ_MESH) meshes.push_back(shapes[i]); // (walked with the tightest limit)
+            else others.push_back(shapes[i]);
+        }
+        others.insert(others.end(), meshes.begin(), meshes.end());
+        for (int k = 0; k < 3; k++) scan_header.n_axis[k] = static_cast<int32_t>(units[k].size());
+        scan_header.n_spheres = static_cast<int32_t>(units[3].size());
+        scan_header.n_others = static_cast<int32_t>(others.size());
     }
     dev.mesh_bound_abs = 0;
     for (const DevShape& sh : shapes)
@@ -1147,7 +1234,21 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
         if ((class_mask >> k) & 1u) s->classes.push_back(k);
 
     HIP_TRY(buf.upload(&dev.objects, objects));
-    HIP_TRY(buf.upload(&dev.shapes, shapes));
+    {
+        std::vector<unsigned char> scan(sizeof(ScanHeader) + (units[0].size() + units[1].size() + units[2].size() + units[3].size()) * sizeof(ShapeUnit) +
+                                        others.size() * sizeof(DevShape));
+        unsigned char* at = scan.data();
+        auto append = [&at](const void* src, size_t bytes) {
+            if (bytes) std::memcpy(at, src, bytes);
+            at += bytes;
+        };
+        append(&scan_header, sizeof(scan_header));
+        for (int k = 0; k < 4; k++) append(units[k].data(), units[k].size() * sizeof(ShapeUnit));
+        append(others.data(), others.size() * sizeof(DevShape));
+        const unsigned char* d_scan = nullptr;
+        HIP_TRY(buf.upload(&d_scan, scan));
+        dev.scan = reinterpret_cast<const ScanHeader*>(d_scan);
+    }
     HIP_TRY(buf.upload(&dev.materials, materials));
     HIP_TRY(buf.upload(&dev.media, media));
     HIP_TRY(buf.upload(&dev.maps, maps));
