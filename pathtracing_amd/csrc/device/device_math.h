@@ -341,7 +341,7 @@ PTK_DEV V3 sample_half_vector(const V3& normal, double alpha, Rng& rng) { // :22
 }
 
 PTK_DEV double mis_weight(double pdf_a, double pdf_b) { // src/objects.cpp:464-468 with n_a = n_b = 1
-    return pdf_a / (pdf_a + pdf_b);
+    return pdf_a / (pdf_a + pdf_b); // (IEEE division: a pdf can be infinite, and x / inf is 0 where fdiv gives NaN)
 }
 
 } // namespace ptk

@@ -13,7 +13,7 @@ namespace ptk {
 // thread, shuffles inside a wave, 16 wave sums through LDS, a running carry across tiles.
 __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* block_counts, uint32_t count_stride, uint32_t class_mask, uint32_t rounds,
                                                    const BinInfo* previous, BinInfo* info) {
-    const uint32_t n_blocks = chunk_table(previous, rounds * BLOCK).first_chunk[N_CLASSES];
+    const uint32_t n_blocks = chunk_table(previous, rounds * BLOCK).n_chunks;
     __shared__ uint32_t wave_sums[2][16];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t carry = 0; // the same in every thread
@@ -80,10 +80,10 @@ __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* block_counts, uint3
 __global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathPool pool, const BinInfo* previous, const uint32_t* block_offsets,
                                                        uint32_t count_stride, uint32_t class_mask, uint32_t rounds, uint32_t* list_out) {
     const ChunkTable table = chunk_table(previous, rounds * BLOCK);
-    if (blockIdx.x >= table.first_chunk[N_CLASSES]) return;
+    if (blockIdx.x >= table.n_chunks) return;
     int chunk_class;
     uint32_t first, n;
-    locate_chunk(previous, table, rounds * BLOCK, blockIdx.x, chunk_class, first, n);
+    locate_chunk(table, rounds * BLOCK, blockIdx.x, chunk_class, first, n);
     __shared__ uint32_t counts[BIN_ROUNDS][BLOCK / 64][N_CLASSES];
     const int wave = threadIdx.x >> 6;
     int classes[BIN_ROUNDS];
@@ -164,10 +164,10 @@ __global__ __launch_bounds__(BLOCK) void k_count_classes(PathPool out, const Bin
                                                          uint32_t* block_counts, uint32_t count_stride) {
     __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
     const ChunkTable table = chunk_table(info, rounds * BLOCK);
-    for (uint32_t chunk = blockIdx.x; chunk < table.first_chunk[N_CLASSES]; chunk += gridDim.x) {
+    for (uint32_t chunk = blockIdx.x; chunk < table.n_chunks; chunk += gridDim.x) {
         int chunk_class;
         uint32_t first, n;
-        locate_chunk(info, table, rounds * BLOCK, chunk, chunk_class, first, n);
+        locate_chunk(table, rounds * BLOCK, chunk, chunk_class, first, n);
         uint32_t my_counts[N_CLASSES];
 #pragma unroll
         for (int c = 0; c < N_CLASSES; c++) my_counts[c] = 0;
@@ -571,12 +571,14 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_staging(PathPool in, PathPoo
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     auto active = [&](uint32_t k) { return k < n && (k % 5u) != 3u; };
     if (active(i)) request_record(in, list[i], wave_stage);
+    wait_for_loads();
     for (; i - threadIdx.x < n; i += stride) { // block-uniform trip count
         Record cur{};
         if (active(i)) cur = staged_record(lds_record);
         acc += noise[(i * 2654435761u) & noise_mask]; // a load that is still in flight when the next request is issued
         if (active(i + stride)) request_record(in, list[i + stride], wave_stage);
         acc += noise[(i * 40503u + 17u) & noise_mask];
+        wait_for_loads(); // before the stores, as in k_bounce; the top of the next round reads the staged record unguarded
         if (active(i)) {
             st2(out, PL_RAY0, i, cur.r0.x, cur.r0.y);
             st2(out, PL_RAY1, i, cur.r1.x, cur.r1.y);
@@ -673,6 +675,9 @@ void launch_bounce(const LaunchContext& lc, uint32_t bound, uint32_t rounds, con
     const hipStream_t s = lc.stream;
     const dim3 grid(min(chunk_blocks(bound, rounds), static_cast<uint32_t>(STATISTICS_SLOTS)));
     const Variant v = variant_of(sc, lc.specialised);
+    // the kernels that finish every vertex themselves add their class counts to zeros (add_chunk_counts); an error of
+    // the call is the stream's last error, which the caller checks after the launch
+    if (!v.defer) (void) hipMemset2DAsync(block_counts, count_stride * sizeof(uint32_t), 0, chunk_blocks(bound, rounds) * sizeof(uint32_t), N_CLASSES, s);
 #define PTK_CASE(T, U, D, P, C)                                                                                                    \
     if (v.tris == T && v.uv == U && v.defer == D && v.pass == P && v.cache == C)                                                   \
         return launch_bounce_variant<T, U, D, P, C>(s, grid, sc, b, in, out, res, list, info, rounds, block_counts, count_stride, \

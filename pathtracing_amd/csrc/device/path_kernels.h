@@ -168,6 +168,14 @@ PTK_DEV void load_surface(const SampleResults& res, size_t sid, const double2& c
     }
 }
 
+// __syncthreads for blocks whose waves exchange data through LDS only: the fences order LDS accesses alone, so a wave
+// does not wait at the barrier until its stores to memory have been acknowledged (with __syncthreads it does).
+PTK_DEV void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Statistics without atomics on shared lines: every block adds its totals to its own slot.
 // values: [0] visibility-march segments, [1] extension rays, [2] connections marched,
 // [3] records written for the next bounce, [4] vertices shaded by k_tail after its first round,
@@ -180,7 +188,7 @@ PTK_DEV void add_block_statistics(unsigned long long* slots, uint32_t (*wave_sum
 #pragma unroll
         for (int k = 0; k < N_STATISTICS; k++) wave_sums[threadIdx.x >> 6][k] = mine[k];
     }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < N_STATISTICS) {
         uint32_t total = 0;
         for (int w = 0; w < BLOCK / 64; w++) total += wave_sums[w][threadIdx.x];
@@ -247,30 +255,72 @@ PTK_DEV Vertex next_vertex(const DevScene& sc, const BatchParams& b, const V3& o
 // which is also the order of the records, and are the unit of work of k_bounce (one block works
 // through one chunk at a time) and of the class sort (block_counts has one entry per class and
 // chunk).
+// (Vector types, not arrays: an array that a loop indexes before it is unrolled can end up in scratch memory, and the
+// table is read in every round.)
+typedef uint32_t UInt8 __attribute__((ext_vector_type(8)));
+static_assert(N_CLASSES == 8, "ChunkTable holds one vector element per class");
 struct ChunkTable {
-    uint32_t first_chunk[N_CLASSES + 1]; // chunks of class c: [first_chunk[c], first_chunk[c + 1])
+    UInt8 first_chunk;    // chunks of class c: [first_chunk[c], first_chunk[c + 1]), the last class up to n_chunks
+    uint32_t n_chunks;
+    UInt8 start, count;   // the class segments of the sorted list (BinInfo), read once
 };
 PTK_DEV ChunkTable chunk_table(const BinInfo* info, uint32_t chunk_size) {
     ChunkTable t;
     uint32_t running = 0;
 #pragma unroll
     for (int c = 0; c < N_CLASSES; c++) {
+        // (readfirstlane: the values are the same in every lane, and the compiler is to keep them in scalar registers)
+        t.start[c] = __builtin_amdgcn_readfirstlane(info->start[c]);
+        t.count[c] = __builtin_amdgcn_readfirstlane(info->count[c]);
         t.first_chunk[c] = running;
-        running += (info->count[c] + chunk_size - 1) / chunk_size;
+        running += (t.count[c] + chunk_size - 1) / chunk_size;
     }
-    t.first_chunk[N_CLASSES] = running;
+    t.n_chunks = running;
     return t;
 }
-// class, first record and number of records of a chunk
-PTK_DEV void locate_chunk(const BinInfo* info, const ChunkTable& t, uint32_t chunk_size, uint32_t chunk, int& cls, uint32_t& first,
-                          uint32_t& count) {
+// class, first record and number of records of a chunk (uniform values, selected without indexing the table)
+PTK_DEV void locate_chunk(const ChunkTable& t, uint32_t chunk_size, uint32_t chunk, int& cls, uint32_t& first, uint32_t& count) {
     cls = 0;
+    uint32_t start = t.start[0], total = t.count[0], first_chunk = t.first_chunk[0];
 #pragma unroll
     for (int c = 1; c < N_CLASSES; c++)
-        if (chunk >= t.first_chunk[c]) cls = c;
-    const uint32_t offset = (chunk - t.first_chunk[cls]) * chunk_size;
-    first = info->start[cls] + offset;
-    count = min(chunk_size, info->count[cls] - offset);
+        if (chunk >= t.first_chunk[c]) {
+            cls = c;
+            start = t.start[c];
+            total = t.count[c];
+            first_chunk = t.first_chunk[c];
+        }
+    const uint32_t offset = (chunk - first_chunk) * chunk_size;
+    first = start + offset;
+    count = min(chunk_size, total - offset);
+}
+
+// One round of a block's work: BLOCK records of one chunk, lane t taking record first + r * BLOCK + t of the list.
+struct RoundCursor {
+    uint32_t chunk, first, n, r; // the chunk, its first list entry and record count, the round within it
+    int cls;
+    bool valid;
+};
+PTK_DEV RoundCursor first_round(const ChunkTable& t, uint32_t chunk_size, uint32_t chunk, uint32_t n_chunks) {
+    RoundCursor c{chunk, 0u, 0u, 0u, 0, chunk < n_chunks};
+    if (c.valid) locate_chunk(t, chunk_size, chunk, c.cls, c.first, c.n);
+    return c;
+}
+// the round a block takes after round c: the next of the same chunk, or the first of the block's next chunk
+PTK_DEV RoundCursor next_round(const ChunkTable& t, uint32_t chunk_size, const RoundCursor& c, uint32_t n_chunks) {
+    if (!c.valid) return c;
+    if ((c.r + 1) * BLOCK < c.n) {
+        RoundCursor d = c;
+        d.r++;
+        return d;
+    }
+    return first_round(t, chunk_size, c.chunk + gridDim.x, n_chunks);
+}
+PTK_DEV bool in_round(const RoundCursor& c) {
+    return c.valid && c.r * BLOCK + threadIdx.x < c.n;
+}
+PTK_DEV uint32_t list_entry(const uint32_t* list, const RoundCursor& c) {
+    return in_round(c) ? list[c.first + c.r * BLOCK + threadIdx.x] : 0u;
 }
 
 // Per-class counts of the records a block wrote for one chunk -> block_counts[class][chunk].
@@ -280,13 +330,26 @@ PTK_DEV void store_chunk_counts(uint32_t (*wave_counts)[N_CLASSES], const uint32
 #pragma unroll
         for (int c = 0; c < N_CLASSES; c++) wave_counts[threadIdx.x >> 6][c] = my_counts[c];
     }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < N_CLASSES) {
         uint32_t total = 0;
         for (int w = 0; w < BLOCK / 64; w++) total += wave_counts[w][threadIdx.x];
         block_counts[threadIdx.x * count_stride + chunk] = total;
     }
-    __syncthreads(); // wave_counts is reused by the block's next chunk
+    lds_barrier(); // wave_counts is reused by the block's next chunk
+}
+
+// The same without a barrier, for counts that are zero when the kernel starts: every wave adds what it wrote itself,
+// lane c the count of class c.  (The waves of a block then never wait for one another between chunks; with a barrier
+// per chunk they spent about a sixth of their time waiting for the slowest of the four.)  The counts of a chunk sit
+// in places of their own, so the atomics of different chunks do not queue on one address.
+PTK_DEV void add_chunk_counts(const uint32_t* my_counts, uint32_t* block_counts, uint32_t count_stride, uint32_t chunk) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t mine = 0;
+#pragma unroll
+    for (int c = 0; c < N_CLASSES; c++)
+        if (lane == static_cast<uint32_t>(c)) mine = my_counts[c];
+    if (lane < N_CLASSES && mine != 0) atomicAdd(block_counts + lane * count_stride + chunk, mine);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -364,7 +427,7 @@ __global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, 
                 const unsigned long long mask = __ballot(deferred);
                 const int wave = threadIdx.x >> 6;
                 if ((threadIdx.x & 63) == 0) queue_counts[wave] = static_cast<uint32_t>(__popcll(mask));
-                __syncthreads();
+                lds_barrier();
                 if (threadIdx.x == 0) {
                     unsigned long long total = 0;
                     for (int w = 0; w < BLOCK / 64; w++) total += queue_counts[w];
@@ -372,14 +435,14 @@ __global__ __launch_bounds__(BLOCK) void k_generate(DevScene sc, BatchParams b, 
                         total ? atomicAdd(reinterpret_cast<unsigned long long*>(queues.counters), total | (total << 32)) : 0ull;
                     queue_base = static_cast<uint32_t>(before); // rays and vertices advance together
                 }
-                __syncthreads();
+                lds_barrier();
                 if (deferred) {
                     uint32_t slot = queue_base + lanes_below(mask);
                     for (int w = 0; w < wave; w++) slot += queue_counts[w];
                     queues.vertices[slot] = sid;
                     queues.rays[slot] = RayRequest{org.x, org.y, org.z, dir.x, dir.y, dir.z, rays[0].limit, 2 * sid + 1, static_cast<uint32_t>(rays[0].obj)};
                 }
-                __syncthreads(); // queue_counts and queue_base are rewritten next round
+                lds_barrier(); // queue_counts and queue_base are rewritten next round
             }
             else {
 #pragma unroll
@@ -423,10 +486,16 @@ PTK_DEV void request_record(const PathPool& p, uint32_t i, double2* wave_stage) 
     for (int plane = 0; plane < N_PLANES; plane++)
         __builtin_amdgcn_global_load_lds((GlobalVoidPtr) (p.base + record_offset(i) + plane * RECORD_PLANE_STRIDE), (LdsVoidPtr) (wave_stage + plane * BLOCK), 16, 0, 0);
 }
-PTK_DEV Record staged_record(const double2* stage) {
-    // vmcnt(0): every load this wave has requested, the ones into LDS included, has arrived.  Written out
-    // because the compiler's own wait-count insertion was seen to leave it out in the largest kernels.
+// Every load this wave has requested, the ones into LDS included, has arrived (vmcnt(0); expcnt and lgkmcnt at their
+// maxima, i.e. not waited for).  A wave waits for its staged record here, *before* it issues the stores of the round
+// the request was made in, and not where it reads the record (the top of the next round): the memory counter
+// retires in issue order, so a wait at the top would also wait until every store of the round has been
+// acknowledged, which takes microseconds; waves spent a fifth of their lives parked there.
+PTK_DEV void wait_for_loads() {
     __builtin_amdgcn_s_waitcnt(0x0F70);
+}
+// The record request_record asked for, after wait_for_loads.
+PTK_DEV Record staged_record(const double2* stage) {
     const double2* mine = stage + threadIdx.x;
     Record r;
     r.r0 = mine[PL_RAY0 * BLOCK];
@@ -495,7 +564,7 @@ PTK_DEV void shade_vertex(const DevScene& sc, const SampleResults& res, const De
             LightSample ls;
             if (pick_light_point<TRIS>(sc, -1, point, ls, rng)) {
                 double weight = mis_weight(ls.light_pdf, PHASE_ISOTROPIC);
-                sh_contrib = thr * (weight * PHASE_ISOTROPIC / ls.light_pdf * static_cast<double>(sc.n_lights));
+                sh_contrib = thr * (fdiv(weight * PHASE_ISOTROPIC, ls.light_pdf) * static_cast<double>(sc.n_lights));
                 sh_dir = ls.direction;
                 sh_dist = ls.distance;
                 sh_key = rng_fork(rng.key, rng.ctr);
@@ -552,7 +621,7 @@ PTK_DEV void shade_vertex(const DevScene& sc, const SampleResults& res, const De
                     double cosine = fmax(dot(s.normal, ls.direction), 0.0);
                     if (!wrong_side && cosine > 0) {
                         double weight = mis_weight(ls.light_pdf, pdf);
-                        sh_contrib = brdf * thr * (weight * cosine / ls.light_pdf * static_cast<double>(sc.n_lights));
+                        sh_contrib = brdf * thr * (fdiv(weight * cosine, ls.light_pdf) * static_cast<double>(sc.n_lights));
                         sh_dir = ls.direction;
                         sh_dist = ls.distance;
                         sh_key = key;
@@ -632,7 +701,10 @@ PTK_DEV bool shade_record(const DevScene& sc, const BatchParams& b, const Sample
     if (static_cast<int>(v.depth) >= sc.min_depth) {
         double threshold = fmin(vmax(v.thr), 0.9);
         allow = v.rng.u01() < threshold;
-        if (allow) v.thr = v.thr / threshold;
+        if (allow) { // (one reciprocal for the three quotients)
+            const double r = frcp(threshold);
+            v.thr = v3(fdiv_by(v.thr.x, threshold, r), fdiv_by(v.thr.y, threshold, r), fdiv_by(v.thr.z, threshold, r));
+        }
     }
     return allow && static_cast<int>(v.depth) + 1 <= sc.max_depth;
 }
@@ -665,8 +737,7 @@ PTK_DEV Vertex close_vertex(const DevScene& sc, PathVertex& v, bool alive, doubl
                                               stat[0], shadow_hit);
         v.color = v.color + v.sh_contrib * visible;
     }
-    Vertex nv;
-    nv.cls = -1;
+    Vertex nv{0.0, -1, 0, -1};
     if (alive) {
         stat[1]++;
         nv = vertex_of(extension_hit, scatter_distance);
@@ -766,7 +837,7 @@ PTK_DEV DevScene stage_scene(const DevScene& sc, double* lds) {
         for (uint32_t i = threadIdx.x; i < n_obj; i += blockDim.x) lds[i] = src_obj[i];
         for (uint32_t i = threadIdx.x; i < n_light; i += blockDim.x) lds[n_obj + i] = src_light[i];
         for (uint32_t i = threadIdx.x; i < n_med; i += blockDim.x) lds[n_obj + n_light + i] = src_med[i];
-        __syncthreads();
+        lds_barrier();
         out.objects = reinterpret_cast<const DevObject*>(lds);
         out.light_objects = reinterpret_cast<const DevObject*>(lds + n_obj);
         out.media = reinterpret_cast<const DevMedium*>(lds + n_obj + n_light);
@@ -789,7 +860,6 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
     __shared__ double2 lds_record[STAGE ? N_PLANES * BLOCK : 1];
     double2* const wave_stage = lds_record + 64 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
-    __shared__ uint32_t wave_counts[BLOCK / 64][N_CLASSES];
     __shared__ uint32_t queue_counts[BLOCK / 64][2];
     __shared__ uint32_t queue_base[2];
     PTK_TRAVERSAL_STACK(st, lds_stack, sc_global);
@@ -800,128 +870,140 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
 #define PTK_STAMP(k)                                                                                   \
     {                                                                                                  \
         const uint64_t now_ = __builtin_readcyclecounter();                                            \
-        if ((threadIdx.x & 63) == 0) stat[(k) == 2 ? 5 : 6 + (k)] += static_cast<uint32_t>((now_ - stamp_) >> 4); \
+        if ((threadIdx.x & 63) == 0) stat[(k) == 3 ? 4 : (k) == 2 ? 5 : 6 + (k)] += static_cast<uint32_t>((now_ - stamp_) >> 4); \
         stamp_ = now_;                                                                                 \
     }
     uint64_t stamp_ = __builtin_readcyclecounter();
 #else
 #define PTK_STAMP(k)
 #endif
-    for (uint32_t chunk = blockIdx.x; chunk < table.first_chunk[N_CLASSES]; chunk += gridDim.x) {
-        int cls;
-        uint32_t first, n;
-        locate_chunk(info, table, rounds * BLOCK, chunk, cls, first, n);
-        uint32_t stat[N_STATISTICS] = {};
-        uint32_t my_counts[N_CLASSES];
+    // A block works through the rounds of its chunks (chunk blockIdx.x, then every gridDim.x-th) as one sequence,
+    // software-pipelined across the chunk boundaries: the record of the next round is requested in the middle of the
+    // current one (after the table lookups of shading, before the two ray casts) and its list entry one round earlier
+    // still, whether that round belongs to the same chunk or opens the block's next one.  Only the block's very first
+    // record is waited for with nothing to do.  (When every chunk began with its own dependent pair of loads, list entry
+    // then record, waves spent a fifth of their lives at the tops of chunks.)
+    const uint32_t n_chunks = table.n_chunks;
+    uint32_t stat[N_STATISTICS] = {};
+    uint32_t my_counts[N_CLASSES];
 #pragma unroll
-        for (int c = 0; c < N_CLASSES; c++) my_counts[c] = 0;
-        // Software pipeline over the rounds of the chunk: the record of the next round is requested
-        // in the middle of the current one (after the table lookups of shading, before the two ray
-        // casts), and its list entry one round earlier still, so neither latency is paid at the top.
-        uint32_t qi = threadIdx.x;
-        Record cur{};
-        uint32_t src = qi < n ? list[first + qi] : 0u;
-        if (qi < n) {
+    for (int c = 0; c < N_CLASSES; c++) my_counts[c] = 0;
+    RoundCursor c0 = first_round(table, rounds * BLOCK, blockIdx.x, n_chunks);
+    RoundCursor c1 = next_round(table, rounds * BLOCK, c0, n_chunks);
+    Record cur{};
+    {
+        const uint32_t src = list_entry(list, c0);
+        if (in_round(c0)) {
             if (STAGE) request_record(in, src, wave_stage);
             else cur = load_record(in, src);
         }
-        uint32_t src_next = qi + BLOCK < n ? list[first + qi + BLOCK] : 0u;
-        for (uint32_t r = 0; r * BLOCK < n; r++, qi += BLOCK) {
-            const bool have = qi < n, have_next = qi + BLOCK < n;
-            const uint32_t dst = first + qi;
-            int new_cls = -1;
-            if (STAGE && have) cur = staged_record(lds_record);
-            // The list entry requested a round ago is consumed here on every path: were it still on its way
-            // on some path when its register is reused below, the wait for it would be placed after the
-            // record requests of this round and would wait for them as well (loads return in order).
-            asm volatile("" : : "v"(src_next));
-            Record nxt{};
-            uint32_t src_after = 0;
-            RayState rays[2];
-            bool deferred = false;
-            V3 origin = v3(0.0);
-            if (have) {
-                PathVertex v;
-                const bool alive = shade_record<TRIS, UV>(sc, b, res, cur, cls, v);
-                PTK_STAMP(0)
-
-                // Request the next round's record and the list entry of the one after.  Not earlier: registers
-                // would be held all through shading, and the compiler makes every read of the scene tables in
-                // LDS wait for outstanding loads into LDS; the object scan that follows reads none.
-                if (have_next) {
-                    if (STAGE) request_record(in, src_next, wave_stage);
-                    else nxt = load_record(in, src_next);
-                }
-                if (qi + 2 * BLOCK < n) src_after = list[first + qi + 2 * BLOCK];
-
-                // the shadow ray of the connection and the extension ray leave the vertex together
-                double scatter_distance = INF;
-                if (alive) scatter_distance = free_flight_distance(sc, b, medium_bits_of(v), v.sid, v.rng.ctr);
-                vertex_rays<TRIS>(sc, v, alive, scatter_distance, rays);
-                scan_objects<TRIS, DEFER ? MESH_DEFER : MESH_INLINE, 2>(sc, v.point, rays, st);
-                PTK_STAMP(1)
-                deferred = DEFER && (rays[0].needs_mesh || rays[1].needs_mesh);
-                origin = v.point;
-                if (!deferred) new_cls = finish_vertex<TRIS, UV, PASS>(sc, out, res, dst, v, alive, scatter_distance, hit_of(sc, rays[0]), hit_of(sc, rays[1]), st, stat);
-                else store_pending(out, queues, dst, v, alive, scatter_distance);
-                PTK_STAMP(2)
-            }
-            if (DEFER) { // queue the deferred vertices of this round and their rays: one atomic per block
-                const uint32_t my_rays = deferred ? (rays[0].needs_mesh ? 1u : 0u) + (rays[1].needs_mesh ? 1u : 0u) : 0u;
-                const unsigned long long vertex_mask = __ballot(deferred);
-                uint32_t rays_before = my_rays; // inclusive scan over the wave
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    uint32_t up = __shfl_up(rays_before, off);
-                    if ((threadIdx.x & 63) >= static_cast<uint32_t>(off)) rays_before += up;
-                }
-                const int wave = threadIdx.x >> 6;
-                if ((threadIdx.x & 63) == 63) {
-                    queue_counts[wave][0] = rays_before;
-                    queue_counts[wave][1] = static_cast<uint32_t>(__popcll(vertex_mask));
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    // both counters with one 64-bit atomic (rays in the low half, which never carries: a batch queues
-                    // fewer than 2^32 rays): their one address serves about a hundred atomics per microsecond
-                    unsigned long long total = 0;
-                    for (int w = 0; w < BLOCK / 64; w++) total += queue_counts[w][0] + (static_cast<unsigned long long>(queue_counts[w][1]) << 32);
-                    const unsigned long long before = total ? atomicAdd(reinterpret_cast<unsigned long long*>(queues.counters), total) : 0ull;
-                    queue_base[0] = static_cast<uint32_t>(before);
-                    queue_base[1] = static_cast<uint32_t>(before >> 32);
-                }
-                __syncthreads();
-                if (deferred) {
-                    uint32_t ray_slot = queue_base[0] + rays_before - my_rays, vertex_slot = queue_base[1] + lanes_below(vertex_mask);
-                    for (int w = 0; w < wave; w++) {
-                        ray_slot += queue_counts[w][0];
-                        vertex_slot += queue_counts[w][1];
-                    }
-                    queues.vertices[vertex_slot] = dst;
-#pragma unroll
-                    for (int k = 0; k < 2; k++) {
-                        if (rays[k].needs_mesh) {
-                            // t_max is the closest hit among the other objects: the walk starts culled
-                            queues.rays[ray_slot++] = RayRequest{origin.x, origin.y, origin.z, rays[k].dir.x, rays[k].dir.y, rays[k].dir.z,
-                                                                 rays[k].limit, 2 * dst + k, static_cast<uint32_t>(rays[k].obj)};
-                        }
-                        else queues.results[2 * dst + k] = RayResult{rays[k].limit, rays[k].obj, rays[k].prim}; // what the scan found
-                    }
-                }
-                __syncthreads(); // queue_counts and queue_base are rewritten next round
-            }
-            if (!DEFER) { // (a deferring kernel writes part of the chunk's records only: k_count_classes counts afterwards)
-#pragma unroll
-                for (int c = 0; c < N_CLASSES; c++)
-                    if ((sc.class_mask >> c) & 1u) my_counts[c] += static_cast<uint32_t>(__popcll(__ballot(new_cls == c)));
-            }
-            if (!STAGE) cur = nxt;
-            src = src_next;
-            src_next = src_after;
-        }
-        if (!DEFER) store_chunk_counts(wave_counts, my_counts, block_counts, count_stride, chunk);
-        add_block_statistics(statistics, wave_sums, stat);
     }
+    uint32_t src_next = list_entry(list, c1);
+    if (STAGE) wait_for_loads();
+    while (c0.valid) {
+        const RoundCursor c2 = next_round(table, rounds * BLOCK, c1, n_chunks);
+        const bool have = in_round(c0);
+        const uint32_t dst = c0.first + c0.r * BLOCK + threadIdx.x;
+        int new_cls = -1;
+        if (STAGE && have) cur = staged_record(lds_record);
+        PTK_STAMP(3)
+        // The list entry requested a round ago is consumed here on every path: were it still on its way
+        // on some path when its register is reused below, the wait for it would be placed after the
+        // record requests of this round and would wait for them as well (loads return in order).
+        asm volatile("" : : "v"(src_next));
+        Record nxt{};
+        RayState rays[2];
+        bool deferred = false;
+        V3 origin = v3(0.0);
+        PathVertex v;
+        bool alive = false;
+        if (have) alive = shade_record<TRIS, UV>(sc, b, res, cur, c0.cls, v);
+        PTK_STAMP(0)
+        // Request the next round's record and the list entry of the one after.  Not earlier: registers
+        // would be held all through shading, and the compiler makes every read of the scene tables in
+        // LDS wait for outstanding loads into LDS; the object scan that follows reads none.  (Lanes beyond the end
+        // of this round's chunk take part: the next round may be the first of another chunk.)
+        if (in_round(c1)) {
+            if (STAGE) request_record(in, src_next, wave_stage);
+            else nxt = load_record(in, src_next);
+        }
+        const uint32_t src_after = list_entry(list, c2);
+        double scatter_distance = INF;
+        if (have) {
+            // the shadow ray of the connection and the extension ray leave the vertex together
+            if (alive) scatter_distance = free_flight_distance(sc, b, medium_bits_of(v), v.sid, v.rng.ctr);
+            vertex_rays<TRIS>(sc, v, alive, scatter_distance, rays);
+            scan_objects<TRIS, DEFER ? MESH_DEFER : MESH_INLINE, 2>(sc, v.point, rays, st);
+        }
+        if (STAGE) wait_for_loads(); // the next round's record has had the scan to arrive; the stores begin below
+        PTK_STAMP(1)
+        if (have) {
+            deferred = DEFER && (rays[0].needs_mesh || rays[1].needs_mesh);
+            origin = v.point;
+            if (!deferred) new_cls = finish_vertex<TRIS, UV, PASS>(sc, out, res, dst, v, alive, scatter_distance, hit_of(sc, rays[0]), hit_of(sc, rays[1]), st, stat);
+            else store_pending(out, queues, dst, v, alive, scatter_distance);
+        }
+        PTK_STAMP(2)
+        if (DEFER) { // queue the deferred vertices of this round and their rays: one atomic per block
+            const uint32_t my_rays = deferred ? (rays[0].needs_mesh ? 1u : 0u) + (rays[1].needs_mesh ? 1u : 0u) : 0u;
+            const unsigned long long vertex_mask = __ballot(deferred);
+            uint32_t rays_before = my_rays; // inclusive scan over the wave
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t up = __shfl_up(rays_before, off);
+                if ((threadIdx.x & 63) >= static_cast<uint32_t>(off)) rays_before += up;
+            }
+            const int wave = threadIdx.x >> 6;
+            if ((threadIdx.x & 63) == 63) {
+                queue_counts[wave][0] = rays_before;
+                queue_counts[wave][1] = static_cast<uint32_t>(__popcll(vertex_mask));
+            }
+            lds_barrier();
+            if (threadIdx.x == 0) {
+                // both counters with one 64-bit atomic (rays in the low half, which never carries: a batch queues
+                // fewer than 2^32 rays): their one address serves about a hundred atomics per microsecond
+                unsigned long long total = 0;
+                for (int w = 0; w < BLOCK / 64; w++) total += queue_counts[w][0] + (static_cast<unsigned long long>(queue_counts[w][1]) << 32);
+                const unsigned long long before = total ? atomicAdd(reinterpret_cast<unsigned long long*>(queues.counters), total) : 0ull;
+                queue_base[0] = static_cast<uint32_t>(before);
+                queue_base[1] = static_cast<uint32_t>(before >> 32);
+            }
+            lds_barrier();
+            if (deferred) {
+                uint32_t ray_slot = queue_base[0] + rays_before - my_rays, vertex_slot = queue_base[1] + lanes_below(vertex_mask);
+                for (int w = 0; w < wave; w++) {
+                    ray_slot += queue_counts[w][0];
+                    vertex_slot += queue_counts[w][1];
+                }
+                queues.vertices[vertex_slot] = dst;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    if (rays[k].needs_mesh) {
+                        // t_max is the closest hit among the other objects: the walk starts culled
+                        queues.rays[ray_slot++] = RayRequest{origin.x, origin.y, origin.z, rays[k].dir.x, rays[k].dir.y, rays[k].dir.z,
+                                                             rays[k].limit, 2 * dst + k, static_cast<uint32_t>(rays[k].obj)};
+                    }
+                    else queues.results[2 * dst + k] = RayResult{rays[k].limit, rays[k].obj, rays[k].prim}; // what the scan found
+                }
+            }
+            lds_barrier(); // queue_counts and queue_base are rewritten next round
+        }
+        if (!DEFER) { // (a deferring kernel writes part of the chunk's records only: k_count_classes counts afterwards)
+#pragma unroll
+            for (int c = 0; c < N_CLASSES; c++)
+                if ((sc.class_mask >> c) & 1u) my_counts[c] += static_cast<uint32_t>(__popcll(__ballot(new_cls == c)));
+        }
+        if (!STAGE) cur = nxt;
+        src_next = src_after;
+        if (!DEFER && !(c1.valid && c1.chunk == c0.chunk)) { // the last round of its chunk
+            add_chunk_counts(my_counts, block_counts, count_stride, c0.chunk);
+#pragma unroll
+            for (int c = 0; c < N_CLASSES; c++) my_counts[c] = 0;
+        }
+        c0 = c1;
+        c1 = c2;
+    }
+    add_block_statistics(statistics, wave_sums, stat);
 }
 
 constexpr uint32_t TAIL_REFILL_LANES = 16; // idle lanes at which a wave of k_tail fetches new paths

@@ -177,7 +177,7 @@ struct DevScene {
     int32_t has_pass_through;    // some material can let a connection to a light through (allow_direct_light)
     int32_t tables_fit_lds;      // objects + light_objects + media take at most LDS_SCENE_DOUBLES doubles
     int32_t has_axis_rectangles; // ScanHeader::n_axis is not all zero: rays carry the reciprocals of their direction
-    int32_t _pad0;
+    int32_t has_transparency;    // some transparency map holds a value above zero (else no surface lets a ray straight through)
     int32_t width, height;
     int32_t max_depth, min_depth, nee, aa;
     int32_t background_medium, background_is_black;

@@ -26,6 +26,12 @@ PTK_DEV double medium_ior(const DevScene& sc, int medium) {
 
 // Material::sample_transparency_map (src/materials.cpp:76-81): always consumes one number.
 PTK_DEV bool sample_transparency(const DevScene& sc, const DevMaterial& m, const Surface& s, Rng& rng) {
+    // No transparency map of the scene holds anything but zeros: the number is consumed but not computed.  (It would
+    // let the ray through only if it were exactly zero, which one draw in 2^53 is.)
+    if (!sc.has_transparency) {
+        rng.ctr++;
+        return false;
+    }
     double transparency = s.use_uv ? tex1(sc, m.transparency, true, s.u, s.v) : m.c_transparency;
     return rng.u01() <= transparency;
 }
@@ -329,17 +335,53 @@ struct LightSample {
     double distance, light_pdf;
 };
 
+// Rectangle, triangle and mesh lights: a uniform point on the surface (Rectangle::generate_random_surface_point
+// src/objects.cpp:257-261, Triangle::generate_random_surface_point :408-412, ObjectUnion::random_light_point
+// src/objectunion.cpp:137-142); prim: the triangle the point lies on.
+template<bool TRIS>
+PTK_DEV V3 random_area_point(const DevScene& sc, const DevObject& o, int& prim, Rng& rng) {
+    prim = 0;
+    if (TRIS && o.type == PTK_OBJ_TRIANGLE) {
+        prim = static_cast<int>(o.first_tri);
+        return triangle_random_point(sc.tri_hot[o.first_tri], rng);
+    }
+    if (TRIS && o.type == PTK_OBJ_MESH) {
+        prim = mesh_random_primitive(sc, o, rng);
+        return triangle_random_point(sc.tri_hot[prim], rng);
+    }
+    double r1 = rng.uniform(-o.L1 / 2, o.L1 / 2);
+    double r2 = rng.uniform(-o.L2 / 2, o.L2 / 2);
+    return v3(o.v1x, o.v1y, o.v1z) * r1 + v3(o.v2x, o.v2y, o.v2z) * r2 + v3(o.px, o.py, o.pz);
+}
+
 template<bool TRIS>
 PTK_DEV bool pick_light_point(const DevScene& sc, int shaded_object, const V3& from, LightSample& ls, Rng& rng) {
     if (sc.n_lights == 0) return false;                                   // sample_random_light :444-462
     const DevObject& light = sc.light_objects[rng.integer(0, sc.n_lights)];
     ls.light_index = light.index;
     if (ls.light_index == shaded_object) return false;
-    V3 p = random_light_point<TRIS>(sc, light, from, ls.light_pdf, rng);
-    if (ls.light_pdf == 0) return false;
+    const bool by_area = light.type == PTK_OBJ_RECTANGLE || (TRIS && (light.type == PTK_OBJ_TRIANGLE || light.type == PTK_OBJ_MESH));
+    V3 p;
+    int prim = 0;
+    if (by_area) p = random_area_point<TRIS>(sc, light, prim, rng);
+    else {
+        p = random_light_point<TRIS>(sc, light, from, ls.light_pdf, rng);
+        if (ls.light_pdf == 0) return false;
+    }
     V3 d = p - from;
-    ls.distance = len(d);
-    ls.direction = normalize(d);
+    const double distance2 = len2(d);
+    ls.distance = fsqrt(distance2);
+    ls.direction = v3(fdiv(d.x, ls.distance), fdiv(d.y, ls.distance), fdiv(d.z, ls.distance));
+    if (by_area) {
+        // object_light_pdf for these shapes, sharing the unit vector and the squared distance with the connection:
+        // area_to_angle_factor normalises from - p, whose components, length and quotients are those of p - from
+        // with the sign changed, bit for bit, and the sign drops out under fabs.
+        const V3 normal = object_normal<TRIS>(sc, light, p, prim);
+        const double factor = fabs(fdiv(dot(normal, ls.direction), distance2));
+        const double area = TRIS && light.type == PTK_OBJ_MESH ? light.mesh_light_area : light.area;
+        ls.light_pdf = fabs(fdiv(1.0, area * factor));
+        if (ls.light_pdf == 0) return false;
+    }
     return true;
 }
 

@@ -535,8 +535,8 @@ int trace_batch(PtkScene* s, BatchLane& lane, const BatchParams& b) {
                                   BOUNCE_BYTES_PER_CONTINUED * continued + BOUNCE_BYTES_PER_ENDED * (sum_vertices - continued);
     for (int c = 0; c < N_CLASSES; c++) st.class_vertices[c] += class_vertices[c];
 #ifdef PTK_STAMPS
-    std::fprintf(stderr, "wave-cycles/16: shade %llu, object scan %llu, finish %llu; vertices %llu, rays %llu\n", lane.h_rays[6], lane.h_rays[7],
-                 lane.h_rays[5], (unsigned long long) sum_vertices, (unsigned long long) (segments + extensions));
+    std::fprintf(stderr, "wave-cycles/16: wait for the record %llu, shade %llu, object scan %llu, finish %llu; vertices %llu, rays %llu\n", lane.h_rays[4],
+                 lane.h_rays[6], lane.h_rays[7], lane.h_rays[5], (unsigned long long) sum_vertices, (unsigned long long) (segments + extensions));
 #endif
     if (s->dev.has_meshes) { // k_traverse: ray request in, result out, the 112 bytes of a node that hold boxes and children, 72-byte triangle vertices
         const unsigned long long* t = lane.h_rays + N_STATISTICS;
@@ -1216,6 +1216,14 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
                          static_cast<size_t>(LDS_SCENE_DOUBLES) * sizeof(double);
     for (const DevMaterial& m : materials)
         if (lets_light_through(m)) dev.has_pass_through = 1;
+    dev.has_transparency = 0;
+    for (const DevMaterial& m : materials) {
+        if (m.transparency < 0) continue;
+        const PtkMap& map = d->maps[m.transparency];
+        const int64_t texels = static_cast<int64_t>(map.width) * map.height;
+        for (int64_t k = 0; k < texels; k++)
+            if (!(d->map_data[map.offset + k] <= 0)) dev.has_transparency = 1; // (a NaN texel keeps the draws too)
+    }
     for (const DevMaterial& m : materials)
         if (m.needs_uv) dev.needs_uv = 1;
     for (const DevObject& o : objects)
