@@ -12,8 +12,12 @@ partitioned with per-GPU work fixed (weak scaling) in one of two ways (`--partit
   samples  every rank renders its own slice of sample indices of the whole frame; the films are combined
            with one weighted-mean all-reduce (RCCL) at the end of the timed region
   tiles    the frame is N times as tall; every rank owns the interleaved bands of rows `distributed.row_bands`
-           gives it and renders only those pixels; the films are combined by the same collective, which for
-           disjoint pixels is a gather
+           gives it and renders only those pixels; one all-gather of every rank's own bands (1/N of the frame
+           each) assembles the frame on every rank
+
+The line's "ranks" record holds what an efficiency loss at N > 1 would be attributed with: the slowest and the
+fastest rank's time per step, the time of the combine, the bytes a rank contributes to it, and the world size and
+backend as torch.distributed reports them.
 
 `value` is the headline workload (`--workload`, default the reference's scenes/example at 1920x1080).  The default
 run also measures, in the same process, the other half of the metric -- a generated 1,048,576-triangle mesh in the
@@ -56,7 +60,7 @@ def parse_args():
     ap.add_argument("--partition", default="samples", choices=["samples", "tiles"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--mesh-lon", type=int, default=1024)
     ap.add_argument("--mesh-lat", type=int, default=513)
     ap.add_argument("--mesh-steps", type=int, default=8, help="timed steps of the mesh sub-record")
@@ -188,11 +192,21 @@ class Distributed:
             self.torch.cuda.synchronize()
 
     def max_over_ranks(self, seconds):
+        return self.over_ranks(seconds, "MAX")
+
+    def over_ranks(self, value, op):
+        """MIN, MAX or SUM of a per-rank number."""
         if not self.on:
-            return seconds
-        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.torch.device("cuda", self.local_rank))
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            return value
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.torch.device("cuda", self.local_rank))
+        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
         return float(t.item())
+
+    def describe(self):
+        """What the collective library itself reports about the job."""
+        if not self.on:
+            return {"world_size": 1, "backend": None}
+        return {"world_size": self.dist.get_world_size(), "backend": self.dist.get_backend(), "rank_env": self.world}
 
     def close(self):
         if self.on:
@@ -201,7 +215,7 @@ class Distributed:
 
 def run_workload(pt, args, ds, workload, width, height, spp, steps, warmup, code):
     """W untimed steps, then exactly K timed ones between barriers; returns the record of the workload."""
-    from pathtracing_amd.distributed import band_job, combine_films, sample_slice
+    from pathtracing_amd.distributed import FilmCombiner, band_job, sample_slice
     rank, world = ds.rank, ds.world
     tiles = args.partition == "tiles"
     frame_height = height * world if tiles else height  # tiles: per-GPU pixel count fixed, the frame grows
@@ -212,18 +226,20 @@ def run_workload(pt, args, ds, workload, width, height, spp, steps, warmup, code
     W, H = width, frame_height
     n_pixels = W * H
     band_start, own_pixels, band_pixels, band_stride = band_job(rank, world, W, H, band_rows=8) if tiles else (0, n_pixels, 0, 0)
-    scene = pt.DeviceScene(host_scene, max_paths_in_flight=max(width * height * spp, 1 << 22))
+    # at most 2^24 paths in flight: a step of more samples per pixel is traced as several batches of whole pixels
+    scene = pt.DeviceScene(host_scene, max_paths_in_flight=max(min(width * height * spp, 1 << 24), 1 << 22))
     build_s = time.perf_counter() - t_build
 
+    combiner = None
     if ds.on:
+        # the films live in one torch tensor (FilmCombiner) that the library renders into; every buffer the combine
+        # needs is allocated here, before the timed region
         torch = ds.torch
-        dev = torch.device("cuda", ds.local_rank)
-        t_img = torch.zeros(n_pixels * 3, dtype=torch.float64, device=dev)
-        t_pos = torch.zeros(n_pixels * 3, dtype=torch.float64, device=dev)
-        t_nrm = torch.zeros(n_pixels * 3, dtype=torch.float64, device=dev)
-        t_cnt = torch.zeros(n_pixels, dtype=torch.int64, device=dev)
+        combiner = FilmCombiner(n_pixels, torch.device("cuda", ds.local_rank), world, mode=args.partition,
+                                band_pixels=band_pixels if tiles else 0)
         torch.cuda.synchronize()
-        film = pt.Film(W, H, device_buffers=(t_img.data_ptr(), t_pos.data_ptr(), t_nrm.data_ptr(), t_cnt.data_ptr()))
+        film = pt.Film(W, H, device_buffers=(combiner.image.data_ptr(), combiner.position.data_ptr(), combiner.normal.data_ptr(),
+                                             combiner.counters.data_ptr()))
     else:
         film = pt.Film(W, H)
 
@@ -268,7 +284,7 @@ def run_workload(pt, args, ds, workload, width, height, spp, steps, warmup, code
         # the warm-up also runs the combine once: RCCL sets up its channels and torch's allocator gets its
         # blocks at the first large collective, which would otherwise fall inside the timed region
         pt.sync()
-        combine_films(t_img, t_pos, t_nrm, t_cnt)
+        combiner.combine(rank)
         ds.torch.cuda.synchronize()
     ds.barrier(pt)
     film.clear()
@@ -278,12 +294,21 @@ def run_workload(pt, args, ds, workload, width, height, spp, steps, warmup, code
     for i in range(steps):
         step(warmup + i, timed=True)
     pt.sync()
+    render_s = time.perf_counter() - t0  # this rank's K steps
+    combine_s = 0.0
     if ds.on:
-        # combine the per-GPU films: weighted mean over RCCL, once per flush (disjoint pixels: a gather)
-        combine_films(t_img, t_pos, t_nrm, t_cnt)
+        # combine the per-GPU films over RCCL, once per flush: an all-reduce (sample slices) or an all-gather of every
+        # rank's own bands (tiles)
+        t1 = time.perf_counter()
+        combiner.combine(rank)
         ds.torch.cuda.synchronize()
+        combine_s = time.perf_counter() - t1
     ds.barrier(pt)
     elapsed = ds.max_over_ranks(time.perf_counter() - t0)
+    ranks = {"ms_per_step_min": ds.over_ranks(render_s, "MIN") / steps * 1e3, "ms_per_step_max": ds.over_ranks(render_s, "MAX") / steps * 1e3,
+             "combine_ms_max": ds.over_ranks(combine_s, "MAX") * 1e3,
+             "combine_bytes_per_rank": combiner.wire_bytes_per_rank() if combiner else 0}
+    ranks.update(ds.describe())
 
     st = scene.stats()
     total_paths = own_pixels * spp * steps * world
@@ -342,8 +367,8 @@ def run_workload(pt, args, ds, workload, width, height, spp, steps, warmup, code
                      "device_ms": {"k_bounce": fam["k_bounce"][0], "k_bin": fam["k_bin"][0],
                                    "k_traverse": fam["k_traverse"][0], "other": other_ms[0]},
                      "vertices_by_class": {CLASS_NAMES[c]: int(st.class_vertices[c]) for c in range(8) if st.class_vertices[c]}})
-    partition = {"samples": "sample-index slices per GPU, film all-reduce at the end",
-                 "tiles": "interleaved 8-row bands per GPU (the frame is n_gpus times as tall), films gathered at the end"}[args.partition]
+    partition = {"samples": "sample-index slices per GPU, one all-reduce of the films at the end",
+                 "tiles": "interleaved 8-row bands per GPU (the frame is n_gpus times as tall), one all-gather of every GPU's own bands at the end"}[args.partition]
     record = {
         "value": value, "unit": "Mpaths/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
         "config": {"workload": f"{workload_name}, {W}x{H}, {spp} spp per step ({spp * steps} spp in the timed region)",
@@ -357,7 +382,7 @@ def run_workload(pt, args, ds, workload, width, height, spp, steps, warmup, code
                  "nodes_per_traversed_ray": st.nodes_visited / max(st.traversed_rays, 1),
                  "triangles_per_traversed_ray": st.triangles_tested / max(st.traversed_rays, 1),
                  "traversal_stack_overflows": int(st.stack_overflows)},
-        "roofline": roofline,
+        "roofline": roofline, "ranks": ranks,
     }
     return record, host_scene, scene, film
 
@@ -404,7 +429,7 @@ def main():
         "value": record["value"], "unit": "Mpaths/s", "n_gpus": ds.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": record["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic", "config": record["config"], "rays": record["rays"],
-        "roofline": record["roofline"], "device_library_sources": code,
+        "roofline": record["roofline"], "ranks": record["ranks"], "device_library_sources": code,
     }
     if ds.rank == 0 and not args.no_cpu_baseline and ds.world == 1:
         threads = args.cpu_threads or min(16, os.cpu_count() or 1)

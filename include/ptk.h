@@ -267,6 +267,14 @@ int ptk_film_device_pointers(PtkFilm* film, double** image, double** position, d
  * scene's device. */
 int ptk_render(PtkScene* scene, PtkFilm* film, const PtkRenderJob* job);
 
+/* Folds the film `from` into the film `into` (same size; any two devices): per pixel the sample-count-weighted mean of
+ * the two running means with increment_average's arithmetic (app/pathtracer.cpp:232-235), the counters added; a pixel
+ * only one of the films has samples for keeps that film's bits, so films of disjoint pixels merge exactly.  `from` is
+ * left as it is.  Films on different devices are copied device to device (over xGMI between the GPUs of a node), not
+ * through the host.  This is the combine step of several GPUs rendering one image, for which the reference has one
+ * set of buffers shared by its threads (app/pathtracer.cpp:237-275, 337-365).  Returns when the merge is done. */
+int ptk_film_merge(PtkFilm* into, PtkFilm* from);
+
 /* ptk_render for a job whose pixels are not one contiguous run but bands: runs of `band_pixels` pixels that begin
  * `band_stride` pixels apart, the first at job->start_idx; job->number_of_pixels counts the pixels of all bands
  * together (the last band may be shorter).  With band_pixels = rows * W and band_stride = n_gpus * rows * W these are
@@ -280,12 +288,22 @@ int ptk_render_bands(PtkScene* scene, PtkFilm* film, const PtkRenderJob* job, in
 int ptk_render_host(PtkScene* scene, const PtkRenderJob* job, double* image, double* position, double* normal,
                     uint64_t* counters);
 
+/* A copy of `scene` on the current device (the one of the last ptk_init on this thread): the tables, triangles and
+ * hierarchies are copied device to device, nothing is parsed or built again.  Several GPUs rendering one scene build
+ * it once and clone it (the reference builds its one scene once, app/pathtracer.cpp:309-316).  The copy renders
+ * the same bits as the original and is destroyed on its own. */
+int ptk_scene_clone(PtkScene* scene, PtkScene** out);
+
 /* How the mesh hierarchies of a scene were built (no counterpart in the reference, which prints the whole scene set-up
  * time, app/pathtracer.cpp:309-316): the time of the builds of all meshes together in milliseconds (device time of the
  * build kernels for meshes built on the GPU, wall time of the multi-threaded host build otherwise), how many meshes went
  * which way, and the number of 4-wide nodes.  Any pointer may be NULL. */
 int ptk_scene_build_info(PtkScene* scene, double* bvh_build_ms, int32_t* meshes_built_on_gpu, int32_t* meshes_built_on_host,
                          int64_t* bvh_nodes);
+/* The same builds by the host's clock, in milliseconds: for a build on the GPU that is its allocations, the upload of
+ * the vertices, the waits between the levels of the collapse, the download and the bound on the traversal stack
+ * together with the kernels; for a build on the host it is the build itself.  No counterpart in the reference. */
+int ptk_scene_build_wall_ms(PtkScene* scene, double* wall_ms);
 int ptk_get_stats(PtkScene* scene, PtkStats* stats);
 /* Name, as a profiler shows it, of the k_bounce instantiation this scene is traced with (the library compiles one per
  * combination of scene features).  No counterpart in the reference; for benchmark reports. */
@@ -299,7 +317,8 @@ int ptk_set_profiling(int enabled);
  * Unknown names and values out of range fail with PTK_ERR_INVALID.
  *   "tail_records": once at most this many paths of a batch are left, one kernel launch follows each of them to
  *     its end instead of running three launches per bounce (0 switches that off; default 1048576, upper limit
- *     16777216; scenes with meshes switch at four times the value).
+ *     16777216).  Scenes with meshes switch when a quarter of the batch's paths are left, but not below this value
+ *     nor above four times it; a batch of no more paths than this value switches at this value in every scene.
  *   "launch_ahead": 0 to 7 (default 7), the bounces the host queues beyond the newest record count it has read back;
  *     fewer makes the switch to the tail kernel prompt and leaves the device waiting for the host between bounces.
  *   "batch_lanes": 1 traces the batches of a job one after the other; 2 cuts jobs of 2^21 paths or more into
@@ -307,7 +326,10 @@ int ptk_set_profiling(int enabled);
  *     own; 0 (default) does that for scenes with meshes only.
  *   "gpu_bvh_build": 1 builds the hierarchy of every mesh of 1024 triangles or more on the GPU when the next scenes
  *     are created (a linear BVH over Morton-ordered triangles: built in milliseconds, costlier to walk than the
- *     host's surface-area tree); 0 (default) builds on the host.
+ *     host's surface-area tree); 0 (default) builds on the host.  A mesh whose build the device has no memory for
+ *     (about 370 bytes per triangle) is built on the host all the same.
+ *   "gpu_bvh_memory_limit": most device memory, in bytes, one hierarchy build on the GPU may allocate (0, the
+ *     default: no limit); a mesh that would need more is built on the host, exactly as when the device runs out.
  *   "traverse_lanes": 1 (default) walks the hierarchies of queued rays with one lane per ray; 4 with four lanes
  *     per ray, one per child box or triangle (slower as measured).
  *   "specialised_kernels": 1 (default) traces a scene with the kernels compiled for what it contains (no

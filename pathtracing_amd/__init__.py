@@ -237,6 +237,11 @@ class Film:
                                                   counters.ctypes.data_as(_ffi.u64ptr)))
         return image, position, normal, counters
 
+    def merge(self, other):
+        """Folds `other` (a film of the same size, on any device) into this film: the sample-count-weighted mean of the
+        two running means per pixel (ptk_film_merge); `other` is left as it is."""
+        _check_dev(device_lib().ptk_film_merge(self._handle, other._handle))
+
     def device_pointers(self):
         p = [C.c_void_p() for _ in range(4)]
         _check_dev(device_lib().ptk_film_device_pointers(self._handle, *[C.byref(x) for x in p]))
@@ -268,6 +273,16 @@ class DeviceScene:
     @property
     def n_pixels(self):
         return self.settings.width * self.settings.height
+
+    def clone(self):
+        """A copy of this scene on the current device, made device to device without building anything again
+        (ptk_scene_clone)."""
+        other = DeviceScene.__new__(DeviceScene)
+        other.settings = PtkSettings.from_buffer_copy(self.settings)
+        h = C.c_void_p()
+        _check_dev(device_lib().ptk_scene_clone(self._handle, C.byref(h)))
+        other._handle = h
+        return other
 
     def trace_primary(self, job):
         n = job.number_of_pixels
@@ -307,10 +322,14 @@ class DeviceScene:
         return s
 
     def build_info(self):
-        """{'bvh_build_ms', 'meshes_built_on_gpu', 'meshes_built_on_host', 'bvh_nodes'} of this scene's mesh hierarchies."""
-        ms, gpu, host, nodes = C.c_double(), C.c_int32(), C.c_int32(), C.c_int64()
+        """{'bvh_build_ms', 'bvh_build_wall_ms', 'meshes_built_on_gpu', 'meshes_built_on_host', 'bvh_nodes'} of this
+        scene's mesh hierarchies (bvh_build_ms: device time of the build kernels for builds on the GPU; the wall figure
+        includes their allocations, copies and waits)."""
+        ms, gpu, host, nodes, wall = C.c_double(), C.c_int32(), C.c_int32(), C.c_int64(), C.c_double()
         _check_dev(device_lib().ptk_scene_build_info(self._handle, C.byref(ms), C.byref(gpu), C.byref(host), C.byref(nodes)))
-        return {"bvh_build_ms": ms.value, "meshes_built_on_gpu": gpu.value, "meshes_built_on_host": host.value, "bvh_nodes": nodes.value}
+        _check_dev(device_lib().ptk_scene_build_wall_ms(self._handle, C.byref(wall)))
+        return {"bvh_build_ms": ms.value, "bvh_build_wall_ms": wall.value, "meshes_built_on_gpu": gpu.value,
+                "meshes_built_on_host": host.value, "bvh_nodes": nodes.value}
 
     def bounce_kernel(self):
         """Profiler name of the k_bounce instantiation this scene uses."""

@@ -123,11 +123,14 @@ DEVICE_PROTOTYPES = {
     "ptk_film_download": (C.c_int, [C.c_void_p, dptr, dptr, dptr, u64ptr]),
     "ptk_film_device_pointers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "ptk_film_merge": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ptk_scene_clone": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ptk_render": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(PtkRenderJob)]),
     "ptk_render_bands": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(PtkRenderJob), C.c_int64, C.c_int64]),
     "ptk_render_host": (C.c_int, [C.c_void_p, C.POINTER(PtkRenderJob), dptr, dptr, dptr, u64ptr]),
     "ptk_scene_build_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int64)]),
+    "ptk_scene_build_wall_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "ptk_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PtkStats)]),
     "ptk_scene_bounce_kernel": (C.c_char_p, [C.c_void_p]),
     "ptk_reset_stats": (C.c_int, [C.c_void_p]),

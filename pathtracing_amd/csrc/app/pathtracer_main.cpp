@@ -12,13 +12,16 @@
 // done); `--resume 1` picks a render up from those files and continues to samples_per_pixel, drawing the sample
 // indices that are still missing (the reference cannot resume: its random streams are not addressable).
 //
-// Several GPUs (--gpus N: devices 0 .. N-1; --devices: any list): the scene is replicated, one host thread per GPU
+// Several GPUs (--gpus N: devices 0 .. N-1; --devices: any list): the scene is built once, on the first GPU, and
+// copied to the others device to device (ptk_scene_clone: no hierarchy is built twice), one host thread per GPU
 // drives that GPU's own stream, and every iteration is dealt out either as interleaved bands of eight image rows
 // (--partition tiles, the default: a GPU renders all samples of its own pixels) or as slices of the iteration's sample
 // indices (--partition samples: every GPU renders every pixel).  This replaces the reference's pool of threads pulling
-// pixel ranges from a job vector (app/pathtracer.cpp:337-365).  At every flush the per-GPU films are copied to the host
-// and merged, pixel by pixel, as the sample-count-weighted mean, into the mapped files.  The image does not depend on the
-// number of GPUs or on the partition (tiles: bit for bit; samples: up to the rounding of the merged mean).
+// pixel ranges from a job vector (app/pathtracer.cpp:337-365).  At every flush the per-GPU films are folded, on the
+// first GPU, into one film (ptk_film_merge: device-to-device copies over xGMI and one kernel per film, the
+// sample-count-weighted mean per pixel), and that one film is copied into the mapped files: one film crosses PCIe per
+// flush, however many GPUs render.  The image does not depend on the number of GPUs or on the partition (tiles: bit for
+// bit; samples: up to the rounding of the merged mean).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -161,13 +164,34 @@ int main(int argc, char* argv[]) {
         return die(ptk_host_last_error());
     if (devices.empty()) devices.push_back(0);
     std::vector<Worker> workers(devices.size());
-    for (size_t k = 0; k < workers.size(); k++) { // the scene is replicated: every GPU builds its own copy
-        workers[k].device = devices[k];
-        if (ptk_init(devices[k]) != PTK_OK) return die(ptk_last_error());
-        if (ptk_scene_create(ptk_host_scene_desc(loaded), 0, &workers[k].scene) != PTK_OK) return die(ptk_last_error());
-        if (ptk_film_create(settings.width, settings.height, &workers[k].film) != PTK_OK) return die(ptk_last_error());
-    }
+    // the scene is built once, on the first GPU ...
+    workers[0].device = devices[0];
+    if (ptk_init(devices[0]) != PTK_OK) return die(ptk_last_error());
+    if (ptk_scene_create(ptk_host_scene_desc(loaded), 0, &workers[0].scene) != PTK_OK) return die(ptk_last_error());
+    if (ptk_film_create(settings.width, settings.height, &workers[0].film) != PTK_OK) return die(ptk_last_error());
     ptk_host_free_scene(loaded);
+    // ... and copied to the others, device to device, all at once
+    {
+        std::vector<std::thread> threads;
+        for (size_t k = 1; k < workers.size(); k++) {
+            workers[k].device = devices[k];
+            threads.emplace_back([&workers, &settings, k] {
+                Worker& w = workers[k];
+                if ((w.status = ptk_init(w.device)) == PTK_OK && (w.status = ptk_scene_clone(workers[0].scene, &w.scene)) == PTK_OK)
+                    w.status = ptk_film_create(settings.width, settings.height, &w.film);
+                if (w.status != PTK_OK) w.error = ptk_last_error();
+            });
+        }
+        for (std::thread& t : threads) t.join();
+        for (const Worker& w : workers)
+            if (w.status != PTK_OK) return die(w.error);
+    }
+    // several GPUs: the film their films are folded into at every flush, on the first GPU
+    PtkFilm* assembled = nullptr;
+    if (workers.size() > 1) {
+        if (ptk_init(devices[0]) != PTK_OK) return die(ptk_last_error());
+        if (ptk_film_create(settings.width, settings.height, &assembled) != PTK_OK) return die(ptk_last_error());
+    }
     auto end_build = std::chrono::steady_clock::now();
     std::clog << "Time taken to build scene: " << std::chrono::duration_cast<std::chrono::seconds>(end_build - begin_build).count()
               << "[s]" << std::endl;
@@ -195,15 +219,6 @@ int main(int argc, char* argv[]) {
 
     // a resumed render continues in the first GPU's film; the others start empty and the merge adds them up
     if (resume && ptk_film_upload(workers[0].film, image, position, normal, counters.data()) != PTK_OK) return die(ptk_last_error());
-    // host copies of the other GPUs' films for the merge at every flush
-    std::vector<double> part_image, part_position, part_normal;
-    std::vector<uint64_t> part_counters;
-    if (workers.size() > 1) {
-        part_image.resize(pixel_count * 3);
-        part_position.resize(pixel_count * 3);
-        part_normal.resize(pixel_count * 3);
-        part_counters.resize(pixel_count);
-    }
 
     auto begin = std::chrono::steady_clock::now();
     auto last_flush = begin;
@@ -229,23 +244,17 @@ int main(int argc, char* argv[]) {
         if (flush_every > 0) flush |= (j + 1) % flush_every == 0;
         else flush |= std::chrono::duration_cast<std::chrono::milliseconds>(now - last_flush).count() >= 1000;
         if (flush) {
-            if (ptk_film_download(workers[0].film, image, position, normal, counters.data()) != PTK_OK) return die(ptk_last_error());
-            for (size_t k = 1; k < workers.size(); k++) { // merge: sample-count-weighted mean per pixel
-                if (ptk_film_download(workers[k].film, part_image.data(), part_position.data(), part_normal.data(), part_counters.data()) != PTK_OK)
-                    return die(ptk_last_error());
-                for (size_t p = 0; p < pixel_count; p++) {
-                    const uint64_t add = part_counters[p];
-                    if (add == 0) continue;
-                    const double n_prev = static_cast<double>(counters[p]), n_add = static_cast<double>(add);
-                    for (size_t c = 3 * p; c < 3 * p + 3; c++) {
-                        // a pixel only this GPU has rendered keeps its bits; otherwise increment_average's arithmetic
-                        image[c] = n_prev == 0 ? part_image[c] : (image[c] * n_prev + part_image[c] * n_add) / (n_prev + n_add);
-                        position[c] = n_prev == 0 ? part_position[c] : (position[c] * n_prev + part_position[c] * n_add) / (n_prev + n_add);
-                        normal[c] = n_prev == 0 ? part_normal[c] : (normal[c] * n_prev + part_normal[c] * n_add) / (n_prev + n_add);
-                    }
-                    counters[p] += add;
-                }
+            PtkFilm* whole = workers[0].film;
+            if (assembled) {
+                // Every GPU's film folded into one on the first GPU, in the order of the GPUs: a pixel only one GPU has
+                // rendered keeps its bits, the others get increment_average's arithmetic (ptk_film_merge).  The films
+                // themselves stay as they are and go on accumulating.
+                if (ptk_film_clear(assembled) != PTK_OK) return die(ptk_last_error());
+                for (Worker& w : workers)
+                    if (ptk_film_merge(assembled, w.film) != PTK_OK) return die(ptk_last_error());
+                whole = assembled;
             }
+            if (ptk_film_download(whole, image, position, normal, counters.data()) != PTK_OK) return die(ptk_last_error());
             if (!write_progress(progress, counters)) return die(std::string("cannot write ") + PROGRESS_FILE);
             last_flush = std::chrono::steady_clock::now();
             print_progress(static_cast<int>(100.0 * (j + 1) / iterations));
@@ -270,6 +279,7 @@ int main(int argc, char* argv[]) {
     ptk_host_unmap_buffer(image, file_size, image_fd);
     ptk_host_unmap_buffer(position, file_size, position_fd);
     ptk_host_unmap_buffer(normal, file_size, normal_fd);
+    ptk_film_destroy(assembled);
     for (Worker& w : workers) {
         ptk_film_destroy(w.film);
         ptk_scene_destroy(w.scene);

@@ -302,8 +302,10 @@ int stack_need(const std::vector<BvhNode4>& nodes, int32_t node) {
 // Builds the hierarchy of `n` triangles (9 doubles each, host memory) on the current device, on `stream`.  Returns false
 // when the GPU build does not apply (fewer than 1024 triangles, a tree deeper than `stack_limit` allows, or a HIP
 // error, then left in *error): the caller builds on the host instead.  build_ms: device time of steps 1 to 6.
+// memory_limit: most device memory the build may allocate, 0 for no limit (a build that would need more ends with
+// hipErrorOutOfMemory, like one the device has no room for).
 bool build_bvh4_gpu(const double* vertices, int64_t n64, int max_leaf, int stack_limit, hipStream_t stream, BuiltBvh& result,
-                    double* build_ms, hipError_t* error_out) {
+                    double* build_ms, hipError_t* error_out, size_t memory_limit) {
     hipError_t error = hipSuccess;
     bool ok = false;
     if (n64 < 1024 || n64 > (int64_t(1) << 28)) return false;
@@ -311,9 +313,13 @@ bool build_bvh4_gpu(const double* vertices, int64_t n64, int max_leaf, int stack
     max_leaf = std::min(std::max(max_leaf, 1), 8);
     const uint32_t blocks = (n + BUILD_BLOCK - 1) / BUILD_BLOCK;
     std::vector<void*> allocations;
+    size_t allocated = 0;
     auto alloc = [&](auto** p, size_t count) {
         void* q = nullptr;
-        const hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(**p));
+        const size_t bytes = std::max<size_t>(count, 1) * sizeof(**p);
+        allocated += bytes;
+        // (memory_limit: the build's device memory is capped, as if the device had no more; 0 = no cap)
+        const hipError_t e = memory_limit && allocated > memory_limit ? hipErrorOutOfMemory : hipMalloc(&q, bytes);
         if (e == hipSuccess) allocations.push_back(q);
         *p = static_cast<std::remove_reference_t<decltype(*p)>>(q);
         return e;

@@ -47,7 +47,7 @@ void launch_bounce(const LaunchContext& lc, uint32_t bound, uint32_t rounds, con
 // Name (as the profiler prints it) of the k_bounce instantiation launch_bounce uses for this scene.
 std::string bounce_kernel_name(const DevScene& sc, bool specialised);
 // Every remaining bounce of the paths in `list` (at most `bound` of them) in one launch.  TAIL_RECORDS is the default
-// count at which a batch switches to it (scenes with meshes: four times that), measured on one MI355X: the bounces of
+// count at which a batch switches to it (scenes with meshes earlier: tail_threshold in ptk_api.hip), measured on one MI355X: the bounces of
 // fewer than a million paths no longer fill the device, and three launches per bounce cost more than the sorting
 // they buy.
 constexpr uint32_t TAIL_RECORDS = 1u << 20;
@@ -74,13 +74,20 @@ void launch_primary(hipStream_t s, const DevScene& sc, const BatchParams& b, int
 void launch_selftest_staging(hipStream_t s, uint32_t blocks, const PathPool& in, const PathPool& out, const uint32_t* list, uint32_t n,
                              const double* noise, uint32_t noise_mask, double* sink);
 
+// `from` folded into the film whose buffers come first: per pixel the sample-count-weighted mean of the two running
+// means, with increment_average's arithmetic (both films on the device of the stream).
+void launch_merge_films(hipStream_t s, size_t n_pixels, double* image, double* position, double* normal, unsigned long long* counters,
+                        const double* from_image, const double* from_position, const double* from_normal,
+                        const unsigned long long* from_counters);
+
 // bvh_build.hip: the hierarchy of `n` triangles (9 doubles each, host memory) built on the current device (linear BVH
 // over Morton-ordered triangles, collapsed to 4-wide nodes).  false: not built (fewer than 1024 triangles, a tree
 // that needs more than `stack_limit` stack entries, or a HIP error, left in *error) and the caller builds on the
-// host.  build_ms: device time of the build kernels.
+// host.  build_ms: device time of the build kernels.  memory_limit: most device memory the build may allocate (0: no
+// limit); a build that needs more fails with hipErrorOutOfMemory, as on a device without room for it.
 struct BuiltBvh;
 bool build_bvh4_gpu(const double* vertices, int64_t n, int max_leaf, int stack_limit, hipStream_t stream, BuiltBvh& result, double* build_ms,
-                    hipError_t* error);
+                    hipError_t* error, size_t memory_limit);
 
 // denoise.hip
 void launch_atrous(hipStream_t s, int width, int height, const double* image_in, double* image_out, const double* position,

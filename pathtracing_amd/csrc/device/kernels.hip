@@ -1,5 +1,6 @@
 // Kernels that exist once (class sort, traversal, film accumulation, primary rays) and the launchers of all
 // kernels; the path-tracing kernel templates live in path_kernels.h.
+#include <algorithm>
 #include <string>
 
 #include "path_kernels.h"
@@ -495,6 +496,27 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(BatchParams b, SampleResul
     }
 }
 
+// Folds the film `from` into the film `into`, pixel by pixel, as raytrace_section folds a job into its buffers
+// (increment_average, app/pathtracer.cpp:232-235): the sample-count-weighted mean of the two running means.  A pixel
+// that only one of the films has samples for keeps that film's bits, so films of disjoint pixels merge exactly.
+__global__ __launch_bounds__(BLOCK) void k_merge_films(size_t n_pixels, double* image, double* position, double* normal,
+                                                       unsigned long long* counters, const double* from_image,
+                                                       const double* from_position, const double* from_normal,
+                                                       const unsigned long long* from_counters) {
+    for (size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x; p < n_pixels; p += static_cast<size_t>(gridDim.x) * BLOCK) {
+        const unsigned long long add = from_counters[p];
+        if (add == 0) continue;
+        const unsigned long long prev = counters[p];
+        const double n_prev = static_cast<double>(prev), n_add = static_cast<double>(add);
+        for (size_t c = 3 * p; c < 3 * p + 3; c++) {
+            image[c] = prev == 0 ? from_image[c] : (image[c] * n_prev + from_image[c] * n_add) / (n_prev + n_add);
+            position[c] = prev == 0 ? from_position[c] : (position[c] * n_prev + from_position[c] * n_add) / (n_prev + n_add);
+            normal[c] = prev == 0 ? from_normal[c] : (normal[c] * n_prev + from_normal[c] * n_add) / (n_prev + n_add);
+        }
+        counters[p] = prev + add;
+    }
+}
+
 // Copies per-sample results to [pixel][sample][3] host-order arrays (ptk_trace_samples).
 __global__ __launch_bounds__(BLOCK) void k_gather_samples(BatchParams b, SampleResults res, size_t pixel_base,
                                                           double* color, double* position, double* normal) {
@@ -767,6 +789,14 @@ void launch_accumulate(hipStream_t s, const BatchParams& b, const SampleResults&
                        unsigned long long* pixel_counters) {
     hipLaunchKernelGGL(k_accumulate, dim3(grid_for(b.n_pixels, 4096)), dim3(BLOCK), 0, s, b, res, image, position, normal,
                        pixel_counters);
+}
+
+void launch_merge_films(hipStream_t s, size_t n_pixels, double* image, double* position, double* normal, unsigned long long* counters,
+                        const double* from_image, const double* from_position, const double* from_normal,
+                        const unsigned long long* from_counters) {
+    const uint32_t blocks = static_cast<uint32_t>(std::min<size_t>((n_pixels + BLOCK - 1) / BLOCK, 8192));
+    hipLaunchKernelGGL(k_merge_films, dim3(std::max(blocks, 1u)), dim3(BLOCK), 0, s, n_pixels, image, position, normal, counters,
+                       from_image, from_position, from_normal, from_counters);
 }
 
 void launch_gather_samples(hipStream_t s, const BatchParams& b, const SampleResults& res, size_t pixel_base, double* color,

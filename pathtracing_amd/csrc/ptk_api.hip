@@ -4,6 +4,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -15,6 +18,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "device/kernels.h"
@@ -66,6 +70,9 @@ std::atomic<bool> g_gpu_bvh_build{false};
 // The closest-hit loop takes spheres and rectangles along the coordinate axes in runs of their own (option scan_runs,
 // read when a scene is created; 0: every object in table order through the general loop).
 std::atomic<bool> g_scan_runs{true};
+// Most device memory a hierarchy build on the GPU may allocate, 0 for no limit (option gpu_bvh_memory_limit): a
+// build that needs more falls back to the host, as it does when the device itself has no room.
+std::atomic<int64_t> g_gpu_bvh_memory_limit{0};
 
 int fail(int code, const std::string& message) {
     g_error = message;
@@ -192,6 +199,7 @@ void make_triangle(const double* p, const double* uv, const double* nrm, uint8_t
 
 struct DeviceBuffers {
     std::vector<void*> allocations;
+    std::vector<size_t> bytes; // of each allocation
     DeviceBuffers() = default;
     DeviceBuffers(const DeviceBuffers&) = delete;
     DeviceBuffers& operator=(const DeviceBuffers&) = delete;
@@ -199,12 +207,17 @@ struct DeviceBuffers {
     void free_all() {
         for (void* p : allocations) (void) hipFree(p);
         allocations.clear();
+        bytes.clear();
     }
     template<typename T>
     hipError_t alloc(T** out, size_t count) {
         void* p = nullptr;
-        hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
-        if (e == hipSuccess) allocations.push_back(p);
+        const size_t size = std::max<size_t>(count, 1) * sizeof(T);
+        hipError_t e = hipMalloc(&p, size);
+        if (e == hipSuccess) {
+            allocations.push_back(p);
+            bytes.push_back(size);
+        }
         *out = static_cast<T*>(p);
         return e;
     }
@@ -220,6 +233,7 @@ struct DeviceBuffers {
         auto it = std::find(allocations.begin(), allocations.end(), p);
         if (it != allocations.end()) {
             (void) hipFree(p);
+            bytes.erase(bytes.begin() + (it - allocations.begin()));
             allocations.erase(it);
         }
     }
@@ -275,6 +289,59 @@ struct PtkFilm {
     bool owns_buffers = true;
     double *image = nullptr, *position = nullptr, *normal = nullptr;
     unsigned long long* counters = nullptr;
+    // ptk_film_merge from a film of another device: that film's buffers are copied here, device to device, first
+    double *stage_image = nullptr, *stage_position = nullptr, *stage_normal = nullptr;
+    unsigned long long* stage_counters = nullptr;
+};
+
+// The host thread of a scene's second batch lane: started with the first two-lane job and kept until the scene goes,
+// instead of one thread created and joined per job.
+class LaneWorker {
+public:
+    LaneWorker() : thread_([this] { loop(); }) {}
+    ~LaneWorker() {
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            stop_ = true;
+        }
+        wake_.notify_all();
+        thread_.join();
+    }
+    LaneWorker(const LaneWorker&) = delete;
+    LaneWorker& operator=(const LaneWorker&) = delete;
+    void start(std::function<void()> task) { // one task at a time: wait() before the next
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            task_ = std::move(task);
+            busy_ = true;
+        }
+        wake_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lock(mutex_);
+        done_.wait(lock, [this] { return !busy_; });
+    }
+
+private:
+    void loop() {
+        std::unique_lock<std::mutex> lock(mutex_);
+        for (;;) {
+            wake_.wait(lock, [this] { return stop_ || (busy_ && task_); });
+            if (stop_) return;
+            std::function<void()> task = std::move(task_);
+            task_ = nullptr;
+            lock.unlock();
+            task(); // (the tasks catch their own exceptions)
+            lock.lock();
+            busy_ = false;
+            done_.notify_all();
+        }
+    }
+    std::mutex mutex_;
+    std::condition_variable wake_, done_;
+    std::function<void()> task_;
+    bool busy_ = false, stop_ = false;
+    std::thread thread_; // last: the thread starts when every other member exists
 };
 
 struct PtkScene {
@@ -286,8 +353,10 @@ struct PtkScene {
     BatchLane lanes[2];
     std::vector<int> classes; // queue classes present in the scene
     PtkFilm* host_film = nullptr; // scratch film for ptk_render_host
+    std::unique_ptr<LaneWorker> worker; // the second lane's host thread, from the first two-lane job on
     PtkStats stats{};
     double bvh_build_ms = 0;      // hierarchy builds of all meshes: device time (GPU build) or wall time (host build)
+    double bvh_build_wall_ms = 0; // the same builds by the host's clock: allocations, copies, waits and the stack bound included
     int32_t bvh_meshes_on_gpu = 0, bvh_meshes_on_host = 0;
     int64_t bvh_nodes = 0;
     PtkScene() = default;
@@ -349,18 +418,23 @@ constexpr size_t STATISTICS_BYTES = STATISTICS_VALUES * sizeof(unsigned long lon
 // The stream, summaries and statistics of a lane, once (lane 0: the context's stream; lane 1: one of the scene's own).
 int prepare_lane(const PtkScene* s, BatchLane& lane, bool own_stream) {
     if (lane.ready) return PTK_OK;
+    // Every resource is created only while its handle is still null, so a call that failed part-way is picked up
+    // where it stopped by the next job instead of allocating everything again over the old handles.
     if (own_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
+        if (!lane.stream) HIP_TRY(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
         lane.owns_stream = true;
     }
     else lane.stream = s->ctx->stream;
-    HIP_TRY(lane.fixed.alloc(&lane.d_info, 2));
-    HIP_TRY(lane.fixed.alloc(&lane.d_statistics, STATISTICS_VALUES));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&lane.h_info), INFO_RING * sizeof(BinInfo), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&lane.h_rays), (2 * N_STATISTICS + 1) * sizeof(unsigned long long), hipHostMallocDefault));
-    lane.h_rays[2 * N_STATISTICS] = 0;
-    for (int i = 0; i < INFO_RING; i++) HIP_TRY(hipEventCreateWithFlags(&lane.info_events[i], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&lane.fence, hipEventDisableTiming));
+    if (!lane.d_info) HIP_TRY(lane.fixed.alloc(&lane.d_info, 2));
+    if (!lane.d_statistics) HIP_TRY(lane.fixed.alloc(&lane.d_statistics, STATISTICS_VALUES));
+    if (!lane.h_info) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&lane.h_info), INFO_RING * sizeof(BinInfo), hipHostMallocDefault));
+    if (!lane.h_rays) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&lane.h_rays), (2 * N_STATISTICS + 1) * sizeof(unsigned long long), hipHostMallocDefault));
+        lane.h_rays[2 * N_STATISTICS] = 0;
+    }
+    for (int i = 0; i < INFO_RING; i++)
+        if (!lane.info_events[i]) HIP_TRY(hipEventCreateWithFlags(&lane.info_events[i], hipEventDisableTiming));
+    if (!lane.fence) HIP_TRY(hipEventCreateWithFlags(&lane.fence, hipEventDisableTiming));
     lane.ready = true;
     return PTK_OK;
 }
@@ -369,11 +443,15 @@ struct EventTimer {
     BatchLane* lane;
     bool on; // profiling as it was set when the batch began
     size_t next = 0;
+    hipError_t error = hipSuccess; // the first failed event call; the timings of the batch are then dropped (collect)
     std::vector<std::pair<int, std::pair<size_t, size_t>>> spans; // family, (begin, end)
+    void note(hipError_t e) {
+        if (e != hipSuccess && error == hipSuccess) error = e;
+    }
     hipEvent_t get() {
         if (next == lane->events.size()) {
-            hipEvent_t e;
-            (void) hipEventCreate(&e);
+            hipEvent_t e = nullptr;
+            note(hipEventCreate(&e));
             lane->events.push_back(e);
         }
         return lane->events[next++];
@@ -381,21 +459,38 @@ struct EventTimer {
     void begin(int family) {
         if (!on) return;
         hipEvent_t e = get();
-        (void) hipEventRecord(e, lane->stream);
+        if (e) note(hipEventRecord(e, lane->stream));
         spans.push_back({family, {next - 1, 0}});
     }
     void end() {
         if (!on) return;
         hipEvent_t e = get();
-        (void) hipEventRecord(e, lane->stream);
+        if (e) note(hipEventRecord(e, lane->stream));
         spans.back().second.second = next - 1;
     }
-    void collect() {
-        if (!on) return;
-        (void) hipStreamSynchronize(lane->stream);
+    // Adds the spans' durations to the lane's statistics; returns the first error of any event call of the batch
+    // (nothing is added then: a partial sum would be taken for a measurement).
+    hipError_t collect() {
+        if (!on) return hipSuccess;
+        note(hipStreamSynchronize(lane->stream));
+        while (!lane->events.empty() && !lane->events.back()) lane->events.pop_back(); // (events that could not be created)
+        if (error != hipSuccess) {
+            spans.clear();
+            next = 0;
+            return error;
+        }
+        std::vector<std::pair<int, float>> measured;
         for (auto& sp : spans) {
             float ms = 0;
-            (void) hipEventElapsedTime(&ms, lane->events[sp.second.first], lane->events[sp.second.second]);
+            note(hipEventElapsedTime(&ms, lane->events[sp.second.first], lane->events[sp.second.second]));
+            measured.push_back({sp.first, ms});
+        }
+        spans.clear();
+        next = 0;
+        if (error != hipSuccess) return error;
+        for (auto& m : measured) {
+            const float ms = m.second;
+            const std::pair<int, int> sp{m.first, 0};
             switch (sp.first) {
                 case 0: lane->stats.bounce_ms += ms; break;
                 case 1: lane->stats.bin_ms += ms; break;
@@ -403,10 +498,18 @@ struct EventTimer {
                 default: lane->stats.other_ms += ms; break;
             }
         }
-        spans.clear();
-        next = 0;
+        return hipSuccess;
     }
 };
+
+// The record count at or below which a batch of n_paths paths is handed to the tail kernel.  Scenes without meshes:
+// tail_records.  Scenes with meshes switch earlier, where the hierarchy walks of a bounce no longer fill the device,
+// but not before three quarters of the batch's paths have ended: a quarter of the batch, kept between tail_records
+// and four times tail_records; batches of at most tail_records paths switch at tail_records like any other scene.
+uint64_t tail_threshold(uint32_t tail_records, bool has_meshes, uint32_t n_paths) {
+    if (!has_meshes || n_paths <= tail_records) return tail_records;
+    return std::min<uint64_t>(4ull * tail_records, std::max<uint64_t>(tail_records, n_paths / 4));
+}
 
 // Traces one batch (all samples of a contiguous pixel range) to completion; per-sample results
 // are left in the lane's results.
@@ -480,11 +583,7 @@ int trace_batch(PtkScene* s, BatchLane& lane, const BatchParams& b) {
         timer.begin(1);
         launch_bin(g_stream, s->dev, current, bound, pool_rounds, previous, lane.block_counts, lane.count_stride, info, lane.list);
         timer.end();
-        // (scenes with meshes: four times as early, where the hierarchy walks of a bounce no longer fill the device, but
-        // not before three quarters of a batch's paths have ended)
-        uint64_t tail_at = tail_records;
-        if (s->dev.has_meshes && b.n_paths > tail_records) tail_at = std::min<uint64_t>(4ull * tail_records, std::max<uint64_t>(tail_records, b.n_paths / 4));
-        if (bound <= tail_at) { // few paths left: one launch follows every one of them to its end
+        if (bound <= tail_threshold(tail_records, s->dev.has_meshes != 0, b.n_paths)) { // few paths left: one launch follows every one of them to its end
             timer.begin(0);
             launch_tail(lc, bound, s->dev, b, current, next, lane.results, lane.list, info, lane.d_statistics);
             timer.end();
@@ -560,7 +659,7 @@ int trace_batch(PtkScene* s, BatchLane& lane, const BatchParams& b) {
     st.bounce_bytes += bounce_bytes;
     st.bin_bytes += bb;
     st.algorithmic_bytes += bb + bounce_bytes;
-    timer.collect();
+    HIP_TRY(timer.collect());
     return PTK_OK;
 }
 
@@ -652,35 +751,45 @@ int for_each_batch(PtkScene* s, const PtkRenderJob* job, F&& after_batch, uint32
         BatchLane& other = s->lanes[1];
         // the other lane's stream begins after what the context's stream holds so far (a film cleared or uploaded), and the
         // context's stream goes on after the other lane's work
-        HIP_TRY(hipEventRecord(other.fence, s->ctx->stream));
-        HIP_TRY(hipStreamWaitEvent(other.stream, other.fence, 0));
-        int other_rc = PTK_OK;
-        std::string other_message;
-        std::thread worker([&] {
+        hipError_t e = hipEventRecord(other.fence, s->ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(other.stream, other.fence, 0);
+        if (e != hipSuccess) rc = fail(PTK_ERR_DEVICE, std::string("two-lane job: ") + hipGetErrorString(e));
+        else {
+            if (!s->worker) s->worker.reset(new LaneWorker());
+            int other_rc = PTK_OK;
+            std::string other_message;
+            s->worker->start([&] {
+                try {
+                    other_rc = use(s->ctx);
+                    if (other_rc == PTK_OK) other_rc = run_lane(1);
+                }
+                catch (const std::exception& ex) {
+                    other_rc = fail(PTK_ERR_INVALID, std::string("unexpected error: ") + ex.what());
+                }
+                catch (...) {
+                    other_rc = fail(PTK_ERR_INVALID, "unexpected error");
+                }
+                if (other_rc != PTK_OK) other_message = g_error; // the message is the thread's own
+            });
             try {
-                other_rc = use(s->ctx);
-                if (other_rc == PTK_OK) other_rc = run_lane(1);
+                rc = run_lane(0);
             }
-            catch (const std::exception& e) {
-                other_rc = fail(PTK_ERR_INVALID, std::string("unexpected error: ") + e.what());
+            catch (...) { // the worker is waited for whatever happens here: it works on this frame's variables
+                s->worker->wait();
+                throw;
             }
-            if (other_rc != PTK_OK) other_message = g_error; // the message is the thread's own
-        });
-        try {
-            rc = run_lane(0);
+            s->worker->wait();
+            if (rc == PTK_OK && other_rc != PTK_OK) rc = fail(other_rc, other_message);
+            if (rc == PTK_OK) { // the context's stream goes on after the other lane's work
+                e = hipEventRecord(other.fence, other.stream);
+                if (e == hipSuccess) e = hipStreamWaitEvent(s->ctx->stream, other.fence, 0);
+                if (e != hipSuccess) rc = fail(PTK_ERR_DEVICE, std::string("two-lane job: ") + hipGetErrorString(e));
+            }
+            // nothing of a failed job is left running on the caller's buffers
+            if (rc != PTK_OK) (void) hipStreamSynchronize(other.stream);
         }
-        catch (...) { // the worker is joined whatever happens here
-            worker.join();
-            throw;
-        }
-        worker.join();
-        if (rc == PTK_OK && other_rc != PTK_OK) rc = fail(other_rc, other_message);
-        if (rc == PTK_OK) {
-            HIP_TRY(hipEventRecord(other.fence, other.stream));
-            HIP_TRY(hipStreamWaitEvent(s->ctx->stream, other.fence, 0));
-        }
-        else (void) hipStreamSynchronize(other.stream); // nothing of the failed job is left running on the caller's buffers
     }
+    // on every path out of the job: the lanes' statistics are added to the scene's and cleared
     for (int l = 0; l < n_lanes; l++) {
         add_stats(s->stats, s->lanes[l].stats);
         s->lanes[l].stats = PtkStats{};
@@ -713,7 +822,7 @@ int ptk_init(int device) {
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail(PTK_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", but the kernels are built for gfx950 only");
         if (prop.multiProcessorCount > 0) ctx.compute_units = static_cast<uint32_t>(prop.multiProcessorCount);
-        HIP_TRY(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+        if (!ctx.stream) HIP_TRY(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking)); // (kept if a later step of an earlier call failed)
         void* address = nullptr; // of this device's copy of the static scratch array (the device is current)
         HIP_TRY(hipGetSymbolAddress(&address, HIP_SYMBOL(scratch)));
         if (!address) return fail(PTK_ERR_DEVICE, "ptk_init: the static scratch array has no address on this device");
@@ -748,6 +857,11 @@ int ptk_set_option(const char* name, int64_t value) {
     if (name && std::strcmp(name, "gpu_bvh_build") == 0) {
         if (value != 0 && value != 1) return fail(PTK_ERR_INVALID, "ptk_set_option: gpu_bvh_build must be 0 or 1");
         g_gpu_bvh_build = value != 0;
+        return PTK_OK;
+    }
+    if (name && std::strcmp(name, "gpu_bvh_memory_limit") == 0) { // bytes; read when a scene is created
+        if (value < 0) return fail(PTK_ERR_INVALID, "ptk_set_option: gpu_bvh_memory_limit must not be negative");
+        g_gpu_bvh_memory_limit = value;
         return PTK_OK;
     }
     if (name && std::strcmp(name, "scan_runs") == 0) { // read when a scene is created
@@ -973,9 +1087,18 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
                 BuiltBvh bvh;
                 double build_ms = 0;
                 hipError_t build_error = hipSuccess;
-                if (g_gpu_bvh_build.load() && build_bvh4_gpu(verts, n, max_leaf, stack_limit, ctx->stream, bvh, &build_ms, &build_error))
+                const auto wall0 = std::chrono::steady_clock::now();
+                if (g_gpu_bvh_build.load() && build_bvh4_gpu(verts, n, max_leaf, stack_limit, ctx->stream, bvh, &build_ms, &build_error,
+                                                             static_cast<size_t>(g_gpu_bvh_memory_limit.load())))
                     s->bvh_meshes_on_gpu++;
                 else {
+                    // A build the device has no memory for (some 370 bytes per triangle) is no reason to refuse a scene
+                    // that loads with the option off: the hierarchy is built on the host.  (The error is not sticky;
+                    // reading it clears it.)  Any other HIP error fails the call.
+                    if (build_error == hipErrorOutOfMemory) {
+                        (void) hipGetLastError();
+                        build_error = hipSuccess;
+                    }
                     HIP_TRY(build_error);
                     const auto t0 = std::chrono::steady_clock::now();
                     bvh = build_bvh4(verts, n, max_leaf, d->settings.bvh_n_axis_splits, build_threads, stack_limit);
@@ -983,6 +1106,7 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
                     s->bvh_meshes_on_host++;
                 }
                 s->bvh_build_ms += build_ms;
+                s->bvh_build_wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
                 s->bvh_nodes += static_cast<int64_t>(bvh.nodes.size());
                 // backstop: the builder bounds the stack its tree needs (build_bvh4), so this cannot fail
                 if (bvh.max_stack > std::min(LDS_STACK_DEPTH + SPILL_STACK_DEPTH, QUAD_STACK_DEPTH - 1))
@@ -1300,6 +1424,73 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     PTK_GUARD_END
 }
 
+int ptk_scene_clone(PtkScene* source, PtkScene** out) {
+    if (!source || !out) return fail(PTK_ERR_INVALID, "ptk_scene_clone: null argument");
+    *out = nullptr;
+    DeviceContext* ctx = current_context();
+    if (!ctx) return PTK_ERR_DEVICE;
+    PTK_GUARD_BEGIN
+    std::unique_ptr<PtkScene> s(new PtkScene());
+    s->ctx = ctx;
+    s->dev = source->dev;
+    s->settings = source->settings;
+    s->max_paths = source->max_paths;
+    s->classes = source->classes;
+    s->bvh_build_ms = source->bvh_build_ms;
+    s->bvh_build_wall_ms = source->bvh_build_wall_ms;
+    s->bvh_meshes_on_gpu = source->bvh_meshes_on_gpu;
+    s->bvh_meshes_on_host = source->bvh_meshes_on_host;
+    s->bvh_nodes = source->bvh_nodes;
+    // every table of the source, copied device to device; the description's pointers are moved to the copies
+    const DeviceBuffers& from = source->scene_buffers;
+    DeviceBuffers& to = s->scene_buffers;
+    if (use(source->ctx) != PTK_OK) return PTK_ERR_DEVICE;
+    HIP_TRY(hipStreamSynchronize(source->ctx->stream));
+    if (use(ctx) != PTK_OK) return PTK_ERR_DEVICE;
+    for (size_t i = 0; i < from.allocations.size(); i++) {
+        unsigned char* copy = nullptr;
+        HIP_TRY(to.alloc(&copy, from.bytes[i]));
+        if (source->ctx->device == ctx->device) HIP_TRY(hipMemcpyAsync(copy, from.allocations[i], from.bytes[i], hipMemcpyDeviceToDevice, ctx->stream));
+        else HIP_TRY(hipMemcpyPeerAsync(copy, ctx->device, from.allocations[i], source->ctx->device, from.bytes[i], ctx->stream));
+    }
+    bool all_found = true;
+    auto moved = [&](auto*& pointer) {
+        if (!pointer) return;
+        const unsigned char* p = reinterpret_cast<const unsigned char*>(pointer);
+        for (size_t i = 0; i < from.allocations.size(); i++) {
+            const unsigned char* base = static_cast<const unsigned char*>(from.allocations[i]);
+            if (p >= base && p < base + from.bytes[i]) {
+                pointer = reinterpret_cast<std::remove_reference_t<decltype(pointer)>>(static_cast<unsigned char*>(to.allocations[i]) + (p - base));
+                return;
+            }
+        }
+        all_found = false;
+    };
+    DevScene& dev = s->dev;
+    moved(dev.objects);
+    moved(dev.scan);
+    moved(dev.materials);
+    moved(dev.media);
+    moved(dev.maps);
+    moved(dev.map_data);
+    moved(dev.lights);
+    moved(dev.light_objects);
+    moved(dev.tri_hot);
+    moved(dev.tri_cold);
+    moved(dev.nodes);
+    moved(dev.nodes_quad);
+    moved(dev.light_cumulative_area);
+    moved(dev.light_tri_index);
+    moved(dev.meshes);
+    moved(dev.stack_overflows);
+    if (!all_found) return fail(PTK_ERR_INVALID, "ptk_scene_clone: a table of the source scene lies outside its buffers");
+    HIP_TRY(hipMemsetAsync(dev.stack_overflows, 0, sizeof(uint32_t), ctx->stream)); // the copy counts its own
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = s.release();
+    return PTK_OK;
+    PTK_GUARD_END
+}
+
 void ptk_scene_destroy(PtkScene* scene) {
     if (!scene) return;
     if (scene->ctx && hipSetDevice(scene->ctx->device) == hipSuccess) (void) hipStreamSynchronize(scene->ctx->stream);
@@ -1430,6 +1621,10 @@ void ptk_film_destroy(PtkFilm* f) {
         (void) hipFree(f->normal);
         (void) hipFree(f->counters);
     }
+    (void) hipFree(f->stage_image); // (null unless the film took part in a merge across devices)
+    (void) hipFree(f->stage_position);
+    (void) hipFree(f->stage_normal);
+    (void) hipFree(f->stage_counters);
     delete f;
 }
 
@@ -1469,6 +1664,41 @@ int ptk_film_download(PtkFilm* f, double* image, double* position, double* norma
     if (normal) HIP_TRY(hipMemcpy(normal, f->normal, n * 24, hipMemcpyDeviceToHost));
     if (counters) HIP_TRY(hipMemcpy(counters, f->counters, n * 8, hipMemcpyDeviceToHost));
     return PTK_OK;
+}
+
+int ptk_film_merge(PtkFilm* into, PtkFilm* from) {
+    PTK_GUARD_BEGIN
+    if (!into || !from || into == from) return fail(PTK_ERR_INVALID, "ptk_film_merge: two different films are required");
+    if (into->width != from->width || into->height != from->height) return fail(PTK_ERR_INVALID, "ptk_film_merge: the films differ in size");
+    const size_t n = static_cast<size_t>(into->width) * static_cast<size_t>(into->height);
+    // what has been queued for `from` is finished first: the copy or the kernel below runs on the other film's stream
+    if (use(from->ctx) != PTK_OK) return PTK_ERR_DEVICE;
+    HIP_TRY(hipStreamSynchronize(from->ctx->stream));
+    if (use(into->ctx) != PTK_OK) return PTK_ERR_DEVICE;
+    const hipStream_t stream = into->ctx->stream;
+    const double *src_image = from->image, *src_position = from->position, *src_normal = from->normal;
+    const unsigned long long* src_counters = from->counters;
+    if (from->ctx->device != into->ctx->device) { // device to device (xGMI between the GPUs of a node), no host copy
+        if (!into->stage_image) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&into->stage_image), n * 24));
+        if (!into->stage_position) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&into->stage_position), n * 24));
+        if (!into->stage_normal) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&into->stage_normal), n * 24));
+        if (!into->stage_counters) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&into->stage_counters), n * 8));
+        const int to = into->ctx->device, fr = from->ctx->device;
+        HIP_TRY(hipMemcpyPeerAsync(into->stage_image, to, from->image, fr, n * 24, stream));
+        HIP_TRY(hipMemcpyPeerAsync(into->stage_position, to, from->position, fr, n * 24, stream));
+        HIP_TRY(hipMemcpyPeerAsync(into->stage_normal, to, from->normal, fr, n * 24, stream));
+        HIP_TRY(hipMemcpyPeerAsync(into->stage_counters, to, from->counters, fr, n * 8, stream));
+        src_image = into->stage_image;
+        src_position = into->stage_position;
+        src_normal = into->stage_normal;
+        src_counters = into->stage_counters;
+    }
+    launch_merge_films(stream, n, into->image, into->position, into->normal, into->counters, src_image, src_position, src_normal, src_counters);
+    HIP_TRY(hipGetLastError());
+    // `from` may be rendered into again as soon as the call returns
+    HIP_TRY(hipStreamSynchronize(stream));
+    return PTK_OK;
+    PTK_GUARD_END
 }
 
 int ptk_film_device_pointers(PtkFilm* f, double** image, double** position, double** normal, uint64_t** counters) {
@@ -1566,6 +1796,12 @@ const char* ptk_scene_bounce_kernel(PtkScene* s) {
     if (!s) return "";
     name = bounce_kernel_name(s->dev, g_specialised.load());
     return name.c_str();
+}
+
+int ptk_scene_build_wall_ms(PtkScene* s, double* wall_ms) {
+    if (!s || !wall_ms) return fail(PTK_ERR_INVALID, "ptk_scene_build_wall_ms: null argument");
+    *wall_ms = s->bvh_build_wall_ms;
+    return PTK_OK;
 }
 
 int ptk_scene_build_info(PtkScene* s, double* bvh_build_ms, int32_t* meshes_built_on_gpu, int32_t* meshes_built_on_host, int64_t* bvh_nodes) {
@@ -1715,13 +1951,16 @@ extern "C" {
 
 int ptk_denoise_device(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t width, int32_t height, double* d_image,
                        const double* d_position, const double* d_normal, double* d_scratch) {
+    PTK_GUARD_BEGIN
     DeviceContext* ctx = current_context();
     if (!ctx) return PTK_ERR_DEVICE;
     return denoise_on_device(ctx, tasks, n_tasks, width, height, d_image, d_position, d_normal, d_scratch);
+    PTK_GUARD_END
 }
 
 int ptk_denoise_device_static(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t width, int32_t height, double* d_image,
                               const double* d_position, const double* d_normal) {
+    PTK_GUARD_BEGIN
     DeviceContext* ctx = current_context();
     if (!ctx) return PTK_ERR_DEVICE;
     if (width < 1 || height < 1) return fail(PTK_ERR_INVALID, "ptk_denoise_device_static: empty image");
@@ -1729,6 +1968,7 @@ int ptk_denoise_device_static(const PtkDenoiseTask* tasks, int32_t n_tasks, int3
         return fail(PTK_ERR_MEMORY, "ptk_denoise_device_static: the image has more than 2097152 pixels, the size of the library's static "
                                     "scratch buffer; use ptk_denoise_device with a scratch buffer of your own");
     return denoise_on_device(ctx, tasks, n_tasks, width, height, d_image, d_position, d_normal, ctx->static_scratch);
+    PTK_GUARD_END
 }
 
 int ptk_denoise(const PtkDenoiseTask* tasks, int32_t n_tasks, int32_t width, int32_t height, double* image,

@@ -101,7 +101,10 @@ int main(int argc, char** argv) {
                 v[static_cast<size_t>(9 * i + 3 * j + a)] = c[a] + d;
             }
     }
-    BuiltBvh b = build_bvh4(v.data(), n, max_leaf, 8, 4, stack_limit);
+#ifndef PTK_BVH_CHECK_THREADS
+#define PTK_BVH_CHECK_THREADS 4
+#endif
+    BuiltBvh b = build_bvh4(v.data(), n, max_leaf, 8, PTK_BVH_CHECK_THREADS, stack_limit);
     if (n == 0) {
         std::printf(b.nodes.empty() ? "ok empty\n" : "nodes for an empty mesh\n");
         return b.nodes.empty() ? 0 : 1;

@@ -13,7 +13,8 @@ reference's outputs:
                           position and normal
   denoise.npz             denoise() outputs for several pipelines on a rendered input triple
   helpers.npz             known-answer tables of the pure helper functions
-  converged_example.npz   mean image of the example scene at high sample count (statistical pin)
+  converged_<scene>.npz   mean images of the example, scattering-cloud and gold-mesh scenes at high sample counts
+                          (statistical pin)
 """
 import os
 import sys
@@ -183,7 +184,11 @@ def converged(tmp):
     the counter-based random streams.  PTK_GOLDEN_SPP scales the sample counts (default 16384 for the example scene,
     half of that for the scattering-medium scene)."""
     spp = int(os.environ.get("PTK_GOLDEN_SPP", "16384"))
-    for name, builder, kwargs, n in (("example", scenes.cornell_example, {}, spp), ("cloud", scenes.cloud_box, {}, spp // 2)):
+    only = os.environ.get("PTK_GOLDEN_CONVERGED", "")  # comma-separated names: regenerate those alone
+    for name, builder, kwargs, n in (("example", scenes.cornell_example, {}, spp), ("cloud", scenes.cloud_box, {}, spp // 2),
+                                     ("mesh_gold", scenes.mesh_box, dict(material="gold"), spp)):
+        if only and name not in only.split(","):
+            continue
         d = os.path.join(tmp, "converged_" + name)
         builder(d, WIDTH=48, HEIGHT=32, samples_per_pixel=n, samples_per_iteration=64, **kwargs)
         hs = pt.load_scene_directory(d)

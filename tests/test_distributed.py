@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 import pathtracing_amd as pt
 from pathtracing_amd import scenes
-from pathtracing_amd.distributed import band_job, combine_films, row_bands, sample_slice
+from pathtracing_amd.distributed import FilmCombiner, band_job, combine_films, row_bands, sample_slice
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -70,10 +70,19 @@ def _worker(rank, world, port, scene_dir, mode, out_dir):
             osc.render(pt.make_job(start, n, total_spp, 0, 9), img, pos, nrm, cnt)
     t = [torch.from_numpy(a.reshape(-1)) for a in (img, pos, nrm)]
     tc = torch.from_numpy(cnt.astype(np.int64).reshape(-1))
+    # the benchmark's combiner on copies of the films: one all-reduce (samples) or one all-gather of own bands (rows)
+    n = W * H
+    combiner = FilmCombiner(n, torch.device("cpu"), world, mode="samples" if mode == "samples" else "tiles", band_pixels=8 * W)
+    for dst, src in ((combiner.image, t[0]), (combiner.position, t[1]), (combiner.normal, t[2])):
+        dst[:3 * n].copy_(src)
+    combiner.counters[:n].copy_(tc)
+    combiner.combine(rank)
     combine_films(t[0], t[1], t[2], tc)
     if rank == 0:
         np.savez(os.path.join(out_dir, f"{mode}.npz"), image=t[0].numpy(), position=t[1].numpy(), normal=t[2].numpy(),
-                 counters=tc.numpy())
+                 counters=tc.numpy(), c_image=combiner.image[:3 * n].numpy(), c_position=combiner.position[:3 * n].numpy(),
+                 c_normal=combiner.normal[:3 * n].numpy(), c_counters=combiner.counters[:n].numpy(),
+                 wire=np.array([combiner.wire_bytes_per_rank()]))
     dist.destroy_process_group()
 
 
@@ -96,3 +105,15 @@ def test_two_ranks_reproduce_the_single_process_image(tmp_path, mode):
         np.testing.assert_allclose(got["image"], img.reshape(-1), rtol=1e-12, atol=1e-15)
     np.testing.assert_allclose(got["position"], pos.reshape(-1), rtol=1e-12, atol=1e-15)
     np.testing.assert_allclose(got["normal"], nrm.reshape(-1), rtol=1e-12, atol=1e-15)
+    # FilmCombiner: the gather of disjoint bands moves bits, the all-reduce of sample slices sums means
+    assert np.array_equal(got["c_counters"], cnt.reshape(-1).astype(np.int64))
+    for name, want in (("c_image", img), ("c_position", pos), ("c_normal", nrm)):
+        if mode == "rows":
+            assert np.array_equal(got[name], want.reshape(-1))
+        else:
+            np.testing.assert_allclose(got[name], want.reshape(-1), rtol=1e-12, atol=1e-15)
+    n = W * H
+    if mode == "rows":  # a rank sends its own bands only: half of the frame (3 bands of 8 rows, padded to 4), films and counters
+        assert got["wire"][0] == (9 * 8 + 8) * (32 * 32) // 2
+    else:
+        assert got["wire"][0] == 10 * 8 * n

@@ -26,6 +26,10 @@ def check_line(out, n_gpus):
     assert m["value"] > 0 and m["unit"] == "Mpaths/s" and "triangle OBJ mesh" in m["config"]["workload"]
     assert m["rays"]["nodes_per_traversed_ray"] > 0 and m["rays"]["traversal_stack_overflows"] == 0
     check_roofline(m["roofline"])
+    for record in (d, m):  # what an efficiency loss at N > 1 would be attributed with
+        ranks = record["ranks"]
+        assert ranks["world_size"] == n_gpus and ranks["ms_per_step_max"] >= ranks["ms_per_step_min"] > 0
+        assert ranks["combine_ms_max"] >= 0 and ranks["combine_bytes_per_rank"] >= 0
     return d
 
 
@@ -53,6 +57,9 @@ def test_multi_gpu_path_with_one_rank():
     assert r.returncode == 0, r.stderr[-2000:]
     d = check_line(r.stdout, 1)
     assert d["cpu_baseline"] is None
+    # one all-reduce of the three films and the weights: 10 doubles per pixel
+    assert d["ranks"]["backend"] == "nccl" and d["ranks"]["combine_ms_max"] > 0
+    assert d["ranks"]["combine_bytes_per_rank"] == 10 * 8 * 320 * 180
 
 
 def test_tile_partition_with_one_rank():
@@ -62,4 +69,6 @@ def test_tile_partition_with_one_rank():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = check_line(r.stdout, 1)
-    assert "bands" in d["config"]["partition"]
+    assert "bands" in d["config"]["partition"] and "all-gather" in d["config"]["partition"]
+    # a rank contributes its own bands: 23 bands of 8 rows cover the 180 rows, 9 doubles and a counter per pixel
+    assert d["ranks"]["backend"] == "nccl" and d["ranks"]["combine_bytes_per_rank"] == (9 * 8 + 8) * 320 * 184

@@ -72,6 +72,28 @@ def test_small_meshes_and_lopsided_ones_fall_back_to_the_host_build(scene_dirs):
         assert np.array_equal(a, b)
 
 
+def test_a_build_the_device_has_no_memory_for_falls_back_to_the_host(scene_dirs):
+    """With gpu_bvh_build on, a hierarchy build that runs out of device memory (forced here by capping what the build
+    may allocate) must not refuse a scene that loads with the option off: the mesh is built on the host, no error is
+    left pending, and the scene traces like the host-built one."""
+    hs = pt.load_scene_directory(scene_dirs["thicket"])  # 6000 triangles: about 2 MB of build memory
+    pt.set_option("gpu_bvh_build", 1)
+    pt.set_option("gpu_bvh_memory_limit", 65536)
+    try:
+        starved = pt.DeviceScene(hs)
+    finally:
+        pt.set_option("gpu_bvh_memory_limit", 0)
+        pt.set_option("gpu_bvh_build", 0)
+    info = starved.build_info()
+    assert info["meshes_built_on_gpu"] == 0 and info["meshes_built_on_host"] == 1 and info["bvh_build_wall_ms"] > 0
+    pt.sync()  # (a pending HIP error would surface here)
+    job = pt.make_job(0, hs.settings.width * hs.settings.height, 1, 0, 4)
+    for a, b in zip(starved.trace_primary(job), pt.DeviceScene(hs).trace_primary(job)):
+        assert np.array_equal(a, b)
+    with pytest.raises(Exception):
+        pt.set_option("gpu_bvh_memory_limit", -1)
+
+
 def test_million_triangles_build_time_and_oracle_parity(tmp_path):
     from oracle import binding as ob
     d = str(tmp_path / "big")
@@ -79,7 +101,9 @@ def test_million_triangles_build_time_and_oracle_parity(tmp_path):
     hs = pt.load_scene_directory(d)
     on_host, on_gpu = both_builds(hs)
     host_ms, gpu_ms = on_host.build_info()["bvh_build_ms"], on_gpu.build_info()["bvh_build_ms"]
-    print(f"1,048,576 triangles: host build {host_ms:.0f} ms, GPU build {gpu_ms:.1f} ms")
+    gpu_wall_ms = on_gpu.build_info()["bvh_build_wall_ms"]
+    print(f"1,048,576 triangles: host build {host_ms:.0f} ms, GPU build {gpu_ms:.1f} ms of device time, {gpu_wall_ms:.0f} ms by the host's clock")
+    assert gpu_wall_ms >= gpu_ms
     assert on_gpu.build_info()["meshes_built_on_gpu"] == 1 and 0 < gpu_ms < host_ms / 10
     n = 640 * 360
     primary = pt.make_job(0, n, 1, 0, 4)

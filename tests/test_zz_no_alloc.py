@@ -55,6 +55,39 @@ def test_static_scratch_entry_point_matches_the_allocating_one_twice_in_a_row():
         assert np.array_equal(want, got), (width, height)
 
 
+def _free_device_memory():
+    """Free device memory as the HIP runtime this process already has loaded reports it."""
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+def test_static_scratch_entry_point_allocates_no_device_memory():
+    """The property the entry point exists for: free device memory is the same before and after two calls (one on a
+    larger, one on a smaller image), while the allocating entry point's caller has to bring a scratch buffer."""
+    pt.init(0)
+    lib = pt.device_lib()
+    tasks = pt.make_denoise_tasks(PIPELINE)
+    frames = []
+    for width, height, seed in ((256, 144, 3), (96, 64, 4)):
+        film = pt.Film(width, height)
+        film.upload(*_frame(width, height, seed))
+        frames.append((width, height, film))
+    # once before measuring: whatever the runtime sets up lazily at a first launch of these kernels is in place
+    for width, height, film in frames:
+        img, pos, nrm, _ = [C.c_void_p(p) for p in film.device_pointers()]
+        assert lib.ptk_denoise_device_static(tasks, len(tasks), width, height, img, pos, nrm) == 0
+    pt.sync()
+    before = _free_device_memory()
+    for width, height, film in frames:
+        img, pos, nrm, _ = [C.c_void_p(p) for p in film.device_pointers()]
+        assert lib.ptk_denoise_device_static(tasks, len(tasks), width, height, img, pos, nrm) == 0
+        assert _free_device_memory() == before  # (while the kernels may still be running)
+    pt.sync()
+    assert _free_device_memory() == before
+
+
 def test_static_scratch_entry_point_refuses_images_beyond_its_buffer():
     pt.init(0)
     lib = pt.device_lib()

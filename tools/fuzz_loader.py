@@ -1,6 +1,10 @@
 """Mutates generated scene directories (scenes.random_box) -- JSON keys dropped or retyped, files truncated, bytes of OBJ
 and map files overwritten -- and loads each with the host loader: it must load or fail with an error message, never
-crash.  usage: python tools/fuzz_loader.py <first_seed> <last_seed>; exit status 0 when no load crashed."""
+crash.  usage: python tools/fuzz_loader.py <first_seed> <last_seed>; exit status 0 when no load crashed.
+With PTK_FUZZ_LOADER_EXE set to a build of tests/cpp/load_scene_main.cpp (tools/sanitize_host.sh builds it with the
+address and undefined-behaviour sanitizers), every directory is loaded by that program in a process of its own: any
+exit status but 0, or output that is neither "loaded" nor "error:", counts as a crash."""
+import subprocess
 import json
 import os
 import random
@@ -55,10 +59,22 @@ for seed in range(first, last):
             if rnd.random() < 0.3: data = data[:rnd.randrange(len(data) + 1)]
             open(p, "wb").write(bytes(data))
     print(seed, which, end=" ", flush=True)
-    try:
-        pt.load_scene_directory(d)
-        ok += 1; print("loaded", flush=True)
-    except pt.PtkError as e:
-        err += 1; print("error:", str(e)[:80], flush=True)
+    exe = os.environ.get("PTK_FUZZ_LOADER_EXE")
+    if exe:
+        r = subprocess.run([exe, d], capture_output=True, text=True, timeout=120)
+        line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+        if r.returncode != 0 or not (line.startswith("loaded") or line.startswith("error:")):
+            print("CRASH, exit status", r.returncode, flush=True)
+            print(r.stdout[-2000:], r.stderr[-6000:], flush=True)
+            sys.exit(1)
+        if line.startswith("loaded"): ok += 1
+        else: err += 1
+        print(line[:80], flush=True)
+    else:
+        try:
+            pt.load_scene_directory(d)
+            ok += 1; print("loaded", flush=True)
+        except pt.PtkError as e:
+            err += 1; print("error:", str(e)[:80], flush=True)
     shutil.rmtree(d, ignore_errors=True)
 print("loaded", ok, "refused", err)
