@@ -399,22 +399,34 @@ def test_interleaved_band_jobs_reproduce_the_frame(scene_dirs, name):
         dev.render_bands(whole, pt.make_job(W * (H - 2), 4 * W, 1, 0, 0), 4 * W, 12 * W)
 
 
-@pytest.mark.parametrize("name,builder", [("example", "cornell_example"), ("cloud", "cloud_box")])
-def test_converged_image_matches_the_reference(tmp_path, name, builder):
+# scene, builder, least reference spp, and the tolerances: relative RMSE and mean over the 98 % of pixels that differ
+# least, relative mean absolute error over all pixels
+CONVERGED = [("example", "cornell_example", 32768, 0.05, 0.005, 0.08), ("cloud", "cloud_box", 32768, 0.05, 0.005, 0.08),
+             ("mesh_gold", "mesh_box", 16384, 0.25, 0.03, 0.35)]
+
+
+@pytest.mark.parametrize("name,builder,least_spp,rmse_tol,mean_tol,mae_tol", CONVERGED)
+def test_converged_image_matches_the_reference(tmp_path, name, builder, least_spp, rmse_tol, mean_tol, mae_tol):
     """The GPU's counter-based random streams against the reference's own generators, statistically: a 65,536-spp GPU
-    render of a 48x32 frame against the reference's mean image at 65,536 spp (example) / 32,768 spp (scattering cloud),
-    tests/golden/converged_*.npz.  The estimator has heavy tails (caustic paths through the mirror and glass balls put
-    rare, very bright samples into a few pixels of either image, and quadrupling the sample count of either side does
-    not tame the plain RMSE), so the statistics leave out the 2 % of the pixels that differ most:
+    render of a 48x32 frame against the reference's mean image at 65,536 spp (example) / 32,768 spp (scattering cloud) /
+    16,384 spp (gold mesh of 4096 triangles), tests/golden/converged_*.npz.  The estimator has heavy tails (caustic paths
+    through the mirror and glass balls put rare, very bright samples into a few pixels of either image, and quadrupling
+    the sample count of either side does not tame the plain RMSE), so the statistics leave out the 2 % of the pixels
+    that differ most:
         per-channel relative RMSE over the other 98 %   <= 0.05   (measured: 0.033 example, 0.019 cloud)
         per-channel mean over the same pixels           within 0.5 %   (measured: 0.08 %, 0.24 %)
-        per-channel relative mean absolute error, all pixels   <= 0.08   (measured: 0.055, 0.018)"""
+        per-channel relative mean absolute error, all pixels   <= 0.08   (measured: 0.055, 0.018)
+    The gold mesh is the hardest of the three: light reaches most pixels over glossy bounces between the mesh and the
+    red wall, the plain relative RMSE of its red channel is 2.5 at these sample counts, and the reference image has a
+    quarter of the samples.  Its tolerances are 0.25 / 3 % / 0.35 (measured, worst channel: 0.157 / 1.3 % / 0.25;
+    green and blue 0.054 / 0.5 % / 0.08 and 0.027 / 0.3 % / 0.02)."""
     import os
     from pathtracing_amd import scenes
     ref = np.load(os.path.join(os.path.dirname(__file__), "golden", f"converged_{name}.npz"))
     want = ref["image"].astype(np.float64)
-    assert int(ref["spp"]) >= 32768
-    d = getattr(scenes, builder)(str(tmp_path / name), WIDTH=48, HEIGHT=32)
+    assert int(ref["spp"]) >= least_spp
+    d = str(tmp_path / name)
+    getattr(scenes, builder)(d, WIDTH=48, HEIGHT=32)
     hs = pt.load_scene_directory(d)
     dev, film = pt.DeviceScene(hs), pt.Film(48, 32)
     for k in range(8):
@@ -424,9 +436,9 @@ def test_converged_image_matches_the_reference(tmp_path, name, builder):
     for c in range(3):
         g, w = got[..., c].ravel(), want[..., c].ravel()
         keep = np.argsort((g - w) ** 2)[:-n_outliers]
-        assert np.sqrt(np.mean((g[keep] - w[keep]) ** 2)) / w.mean() <= 0.05, c
-        assert abs(g[keep].mean() - w[keep].mean()) / w[keep].mean() <= 0.005, c
-        assert np.mean(np.abs(g - w)) / w.mean() <= 0.08, c
+        assert np.sqrt(np.mean((g[keep] - w[keep]) ** 2)) / w.mean() <= rmse_tol, c
+        assert abs(g[keep].mean() - w[keep].mean()) / w[keep].mean() <= mean_tol, c
+        assert np.mean(np.abs(g - w)) / w.mean() <= mae_tol, c
 
 
 def test_record_staging_through_lds_delivers_every_record():

@@ -22,10 +22,11 @@ def trimmed_mean_difference(got, want):
 def main():
     spp = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     pt.init(0)
-    for name, builder in (("example", scenes.cornell_example), ("cloud", scenes.cloud_box)):
+    for name, builder in (("example", scenes.cornell_example), ("cloud", scenes.cloud_box), ("mesh_gold", scenes.mesh_box)):
         ref = np.load(os.path.join(ROOT, "tests", "golden", f"converged_{name}.npz"))
         want = ref["image"].astype(np.float64)
-        d = builder(tempfile.mkdtemp(prefix="ptk_conv_"), WIDTH=48, HEIGHT=32)
+        d = tempfile.mkdtemp(prefix="ptk_conv_")
+        builder(d, WIDTH=48, HEIGHT=32)  # (mesh_box returns its triangle count, not the directory)
         hs = pt.load_scene_directory(d)
         dev, film = pt.DeviceScene(hs), pt.Film(48, 32)
         for k in range(spp // 8192):
