@@ -18,8 +18,11 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <iterator>
 #include <map>
+#include <memory>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -263,34 +266,138 @@ CornerRef parse_corner(const std::string& word) {
     return c;
 }
 
+// Runs work(part, n_parts) for part = 0 .. n_parts - 1 on threads of their own; a LoadError any of them throws is
+// kept, and the one of the lowest part (the first in file order) is thrown again here once all have ended.
+template<typename Work>
+void run_parts(int n_parts, Work work) {
+    std::vector<std::unique_ptr<LoadError>> errors(static_cast<size_t>(n_parts));
+    auto guarded = [&](int part) {
+        try {
+            work(part, n_parts);
+        }
+        catch (const LoadError& e) {
+            errors[static_cast<size_t>(part)].reset(new LoadError(e));
+        }
+    };
+    std::vector<std::thread> threads;
+    for (int part = 1; part < n_parts; part++) threads.emplace_back(guarded, part);
+    guarded(0);
+    for (std::thread& t : threads) t.join();
+    for (const auto& e : errors)
+        if (e) throw LoadError(*e);
+}
+
+// A file mapped read-only (empty files map to nothing).
+struct MappedFile {
+    const char* data = nullptr;
+    size_t size = 0;
+    int fd = -1;
+    explicit MappedFile(const std::string& path) {
+        fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) return;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+            close(fd);
+            fd = -1;
+            return;
+        }
+        size = static_cast<size_t>(st.st_size);
+        if (size > 0) {
+            void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) {
+                close(fd);
+                fd = -1;
+                size = 0;
+                return;
+            }
+            data = static_cast<const char*>(m);
+        }
+    }
+    ~MappedFile() {
+        if (data) munmap(const_cast<char*>(data), size);
+        if (fd >= 0) close(fd);
+    }
+    MappedFile(const MappedFile&) = delete;
+    MappedFile& operator=(const MappedFile&) = delete;
+    bool is_open() const { return fd >= 0; }
+};
+
+// The reference reads the file line by line, three times (src/objectunion.cpp:170-253,378-423).  The format is
+// line-oriented and every line stands for itself, so the file is cut at line ends into one part per thread: each part
+// collects its `v`, `vt`, `vn` and `f` lines in order, and the parts are joined in file order, which gives exactly
+// what one pass over the whole file gives (a 1 GB file of 10,485,760 triangles: 8.5 s on one thread, which was two
+// thirds of the whole scene set-up).  Lines are what std::getline makes of the file: cut at '\n', a '\r' before it
+// stays part of the line, a last line without '\n' counts.
 void load_obj(const std::string& file_name, const std::string& asset_root, bool smooth, const ObjTransform& tf,
               PtkLoadedScene& scene, int64_t& first_triangle, int64_t& n_triangles) {
     std::string path = file_name;
     if (!file_exists(path) && !asset_root.empty()) path = asset_root + "/" + file_name;
-    std::ifstream model_file(path);
-    if (!model_file.is_open()) throw LoadError(PTK_ERR_IO, "Could not open file '" + file_name + "'");
+    MappedFile file(path);
+    if (!file.is_open()) throw LoadError(PTK_ERR_IO, "Could not open file '" + file_name + "'");
 
+    // one part per hardware thread, at most 16, for files of a megabyte or more (PTK_OBJ_PARSE_PARTS in the environment
+    // sets the number of parts, 1 to 64, whatever the size of the file: what the tests use to take small files apart)
+    int n_parts = file.size < (size_t(1) << 20) ? 1 : static_cast<int>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
+    if (const char* forced = std::getenv("PTK_OBJ_PARSE_PARTS")) {
+        const int wanted = std::atoi(forced);
+        if (wanted >= 1 && wanted <= 64) n_parts = wanted;
+    }
+    // part k covers [cut[k], cut[k + 1]): cuts lie just behind a '\n'
+    std::vector<size_t> cut(static_cast<size_t>(n_parts) + 1, file.size);
+    cut[0] = 0;
+    for (int k = 1; k < n_parts; k++) {
+        size_t at = std::max(cut[static_cast<size_t>(k) - 1], file.size / static_cast<size_t>(n_parts) * static_cast<size_t>(k));
+        while (at < file.size && file.data[at] != '\n') at++;
+        cut[static_cast<size_t>(k)] = std::min(at + 1, file.size);
+    }
+    struct Part {
+        std::vector<D3> vertices, uvs, normals;
+        std::vector<std::string> faces;
+    };
+    std::vector<Part> parts(static_cast<size_t>(n_parts));
+    run_parts(n_parts, [&](int k, int) {
+        Part& part = parts[static_cast<size_t>(k)];
+        std::string line;
+        for (size_t at = cut[static_cast<size_t>(k)], end = cut[static_cast<size_t>(k) + 1]; at < end;) {
+            const void* newline = std::memchr(file.data + at, '\n', end - at);
+            const size_t line_end = newline ? static_cast<size_t>(static_cast<const char*>(newline) - file.data) : end;
+            line.assign(file.data + at, line_end - at);
+            at = line_end + 1;
+            std::string first = nth_field(line, ' ', 0);
+            if (first == "v") {
+                part.vertices.push_back({parse_double(nth_field(line, ' ', 1), file_name),
+                                         parse_double(nth_field(line, ' ', 2), file_name),
+                                         parse_double(nth_field(line, ' ', 3), file_name)});
+            }
+            else if (first == "vt") {
+                part.uvs.push_back({parse_double(nth_field(line, ' ', 1), file_name),
+                                    parse_double(nth_field(line, ' ', 2), file_name), 0.0});
+            }
+            else if (first == "vn") {
+                part.normals.push_back({parse_double(nth_field(line, ' ', 1), file_name),
+                                        parse_double(nth_field(line, ' ', 2), file_name),
+                                        parse_double(nth_field(line, ' ', 3), file_name)});
+            }
+            else if (first == "f") {
+                part.faces.push_back(line);
+            }
+        }
+    });
     std::vector<D3> vertices, uvs, normals;
     std::vector<std::string> faces;
-    std::string line;
-    while (std::getline(model_file, line)) {
-        std::string first = nth_field(line, ' ', 0);
-        if (first == "v") {
-            vertices.push_back({parse_double(nth_field(line, ' ', 1), file_name),
-                                parse_double(nth_field(line, ' ', 2), file_name),
-                                parse_double(nth_field(line, ' ', 3), file_name)});
-        }
-        else if (first == "vt") {
-            uvs.push_back({parse_double(nth_field(line, ' ', 1), file_name),
-                           parse_double(nth_field(line, ' ', 2), file_name), 0.0});
-        }
-        else if (first == "vn") {
-            normals.push_back({parse_double(nth_field(line, ' ', 1), file_name),
-                               parse_double(nth_field(line, ' ', 2), file_name),
-                               parse_double(nth_field(line, ' ', 3), file_name)});
-        }
-        else if (first == "f") {
-            faces.push_back(line);
+    if (n_parts == 1) {
+        vertices.swap(parts[0].vertices);
+        uvs.swap(parts[0].uvs);
+        normals.swap(parts[0].normals);
+        faces.swap(parts[0].faces);
+    }
+    else {
+        for (Part& part : parts) {
+            vertices.insert(vertices.end(), part.vertices.begin(), part.vertices.end());
+            uvs.insert(uvs.end(), part.uvs.begin(), part.uvs.end());
+            normals.insert(normals.end(), part.normals.begin(), part.normals.end());
+            faces.insert(faces.end(), std::make_move_iterator(part.faces.begin()), std::make_move_iterator(part.faces.end()));
+            part = Part{};
         }
     }
 
@@ -334,60 +441,80 @@ void load_obj(const std::string& file_name, const std::string& asset_root, bool 
     }
 
     first_triangle = static_cast<int64_t>(scene.tri_flags.size());
-    auto emit = [&](const std::string& face, int i1, int i2, int i3) -> bool {
-        CornerRef c[3] = {parse_corner(nth_field(face, ' ', i1)), parse_corner(nth_field(face, ' ', i2)),
-                          parse_corner(nth_field(face, ' ', i3))};
-        if (!(c[0].v_ok && c[1].v_ok && c[2].v_ok)) return false;
-        bool uv_ok = c[0].uv_ok && c[1].uv_ok && c[2].uv_ok;
-        bool n_ok = c[0].n_ok && c[1].n_ok && c[2].n_ok;
-        uint8_t flags = 0;
-        for (int k = 0; k < 3; k++) {
-            if (c[k].v < 0 || c[k].v >= static_cast<long>(vertices.size()))
-                throw LoadError(PTK_ERR_FORMAT, "Vertex index out of range in file '" + file_name + "'");
-            const D3& v = vertices[static_cast<size_t>(c[k].v)];
-            scene.tri_vertices.insert(scene.tri_vertices.end(), {v.x, v.y, v.z});
-        }
-        if (uv_ok) {
-            for (int k = 0; k < 3; k++) {
-                if (c[k].uv < 0 || c[k].uv >= static_cast<long>(uvs.size()))
-                    throw LoadError(PTK_ERR_FORMAT, "Texture index out of range in file '" + file_name + "'");
-                const D3& t = uvs[static_cast<size_t>(c[k].uv)];
-                scene.tri_uv.insert(scene.tri_uv.end(), {t.x, t.y});
-            }
-            flags |= PTK_TRI_HAS_UV;
-        }
-        else {
-            scene.tri_uv.insert(scene.tri_uv.end(), 6, 0.0);
-        }
-        if (n_ok && smooth) {
-            for (int k = 0; k < 3; k++) {
-                if (c[k].n < 0 || c[k].n >= static_cast<long>(normals.size()))
-                    throw LoadError(PTK_ERR_FORMAT, "Normal index out of range in file '" + file_name + "'");
-                const D3& nn = normals[static_cast<size_t>(c[k].n)];
-                scene.tri_normals.insert(scene.tri_normals.end(), {nn.x, nn.y, nn.z});
-            }
-            flags |= PTK_TRI_SMOOTH;
-        }
-        else {
-            scene.tri_normals.insert(scene.tri_normals.end(), 9, 0.0);
-        }
-        scene.tri_flags.push_back(flags);
-        return true;
+    // The faces, again a part per thread: every part emits its triangles into arrays of its own, which are appended to
+    // the scene's in the order of the parts.
+    struct Emitted {
+        std::vector<double> tri_vertices, tri_uv, tri_normals;
+        std::vector<uint8_t> tri_flags;
     };
-
-    for (const std::string& face : faces) {
-        int spaces = count_char(face, ' ');
-        if (spaces == 3) {
-            emit(face, 1, 2, 3);
-        }
-        else if (spaces == 4) {
-            // the second half of a quad follows the first's success (src/objectunion.cpp:404-419)
-            if (emit(face, 1, 2, 3)) {
-                if (!emit(face, 1, 3, 4))
-                    throw LoadError(PTK_ERR_FORMAT, "Malformed quad face in file '" + file_name + "'");
+    const int face_parts = faces.size() < 65536 && !std::getenv("PTK_OBJ_PARSE_PARTS") ? 1 : n_parts;
+    std::vector<Emitted> emitted(static_cast<size_t>(face_parts));
+    run_parts(face_parts, [&](int k, int n) {
+        Emitted& out = emitted[static_cast<size_t>(k)];
+        auto emit = [&](const std::string& face, int i1, int i2, int i3) -> bool {
+            CornerRef c[3] = {parse_corner(nth_field(face, ' ', i1)), parse_corner(nth_field(face, ' ', i2)),
+                              parse_corner(nth_field(face, ' ', i3))};
+            if (!(c[0].v_ok && c[1].v_ok && c[2].v_ok)) return false;
+            bool uv_ok = c[0].uv_ok && c[1].uv_ok && c[2].uv_ok;
+            bool n_ok = c[0].n_ok && c[1].n_ok && c[2].n_ok;
+            uint8_t flags = 0;
+            for (int j = 0; j < 3; j++) {
+                if (c[j].v < 0 || c[j].v >= static_cast<long>(vertices.size()))
+                    throw LoadError(PTK_ERR_FORMAT, "Vertex index out of range in file '" + file_name + "'");
+                const D3& v = vertices[static_cast<size_t>(c[j].v)];
+                out.tri_vertices.insert(out.tri_vertices.end(), {v.x, v.y, v.z});
             }
+            if (uv_ok) {
+                for (int j = 0; j < 3; j++) {
+                    if (c[j].uv < 0 || c[j].uv >= static_cast<long>(uvs.size()))
+                        throw LoadError(PTK_ERR_FORMAT, "Texture index out of range in file '" + file_name + "'");
+                    const D3& t = uvs[static_cast<size_t>(c[j].uv)];
+                    out.tri_uv.insert(out.tri_uv.end(), {t.x, t.y});
+                }
+                flags |= PTK_TRI_HAS_UV;
+            }
+            else {
+                out.tri_uv.insert(out.tri_uv.end(), 6, 0.0);
+            }
+            if (n_ok && smooth) {
+                for (int j = 0; j < 3; j++) {
+                    if (c[j].n < 0 || c[j].n >= static_cast<long>(normals.size()))
+                        throw LoadError(PTK_ERR_FORMAT, "Normal index out of range in file '" + file_name + "'");
+                    const D3& nn = normals[static_cast<size_t>(c[j].n)];
+                    out.tri_normals.insert(out.tri_normals.end(), {nn.x, nn.y, nn.z});
+                }
+                flags |= PTK_TRI_SMOOTH;
+            }
+            else {
+                out.tri_normals.insert(out.tri_normals.end(), 9, 0.0);
+            }
+            out.tri_flags.push_back(flags);
+            return true;
+        };
+        const size_t begin = faces.size() * static_cast<size_t>(k) / static_cast<size_t>(n),
+                     end = faces.size() * (static_cast<size_t>(k) + 1) / static_cast<size_t>(n);
+        for (size_t f = begin; f < end; f++) {
+            const std::string& face = faces[f];
+            int spaces = count_char(face, ' ');
+            if (spaces == 3) {
+                emit(face, 1, 2, 3);
+            }
+            else if (spaces == 4) {
+                // the second half of a quad follows the first's success (src/objectunion.cpp:404-419)
+                if (emit(face, 1, 2, 3)) {
+                    if (!emit(face, 1, 3, 4))
+                        throw LoadError(PTK_ERR_FORMAT, "Malformed quad face in file '" + file_name + "'");
+                }
+            }
+            // faces with any other number of spaces are silently dropped, as in the reference
         }
-        // faces with any other number of spaces are silently dropped, as in the reference
+    });
+    for (Emitted& part : emitted) {
+        scene.tri_vertices.insert(scene.tri_vertices.end(), part.tri_vertices.begin(), part.tri_vertices.end());
+        scene.tri_uv.insert(scene.tri_uv.end(), part.tri_uv.begin(), part.tri_uv.end());
+        scene.tri_normals.insert(scene.tri_normals.end(), part.tri_normals.begin(), part.tri_normals.end());
+        scene.tri_flags.insert(scene.tri_flags.end(), part.tri_flags.begin(), part.tri_flags.end());
+        part = Emitted{};
     }
     n_triangles = static_cast<int64_t>(scene.tri_flags.size()) - first_triangle;
 }

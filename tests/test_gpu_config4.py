@@ -128,3 +128,63 @@ def test_four_million_triangles_at_4k(tmp_path_factory):
     got, want = dev.trace_samples(job), osc.trace_samples(job)
     ok = np.isclose(got[0].reshape(-1, 3), want[0].reshape(-1, 3), rtol=1e-9, atol=1e-12).all(axis=1)
     assert ok.mean() >= 0.995, ok.mean()
+
+
+def test_ten_million_triangles_at_1080p(tmp_path_factory):
+    """The upper end of configuration 4: a 10,485,760-triangle mesh (gold microfacet) at 1920x1080.  The deepest hierarchy
+    the traversal stack meets (no dropped entry), a film that does not depend on the batch size, the hierarchy from either
+    builder, and a run of pixels across the mesh against the oracle.  Prints where the set-up time goes."""
+    import time
+    from oracle import binding as ob
+    d = str(tmp_path_factory.mktemp("config4_10m"))
+    t0 = time.perf_counter()
+    assert scenes.mesh_box(d, n_lon=4096, n_lat=1281, material="gold", smooth=True, WIDTH=W, HEIGHT=H) == 10485760
+    t1 = time.perf_counter()
+    hs = pt.load_scene_directory(d)
+    t2 = time.perf_counter()
+    dev = pt.DeviceScene(hs)
+    pt.sync()
+    t3 = time.perf_counter()
+    info = dev.build_info()
+    print(f"10,485,760 triangles: OBJ written in {t1 - t0:.1f} s (fixture), host loader {t2 - t1:.2f} s, ptk_scene_create {t3 - t2:.2f} s "
+          f"of which the hierarchy build {info['bvh_build_wall_ms'] / 1e3:.2f} s ({info['bvh_nodes']} nodes)")
+    film = pt.Film(W, H)
+    dev.render(film, pt.make_job(0, N, 2, 0, 31))
+    whole, stats = film.download(), dev.stats()
+    assert stats.paths == 2 * N and stats.stack_overflows == 0 and stats.nodes_visited > stats.traversed_rays > stats.paths
+    assert np.isfinite(whole[0]).all() and (whole[3] == 2).all()
+    # the lower half again in small batches: the same pixels, bit for bit
+    half = pt.Film(W, H)
+    small = pt.DeviceScene(hs, max_paths_in_flight=1_500_000)
+    small.render(half, pt.make_job(N // 2, N // 2, 2, 0, 31))
+    for a, b in zip(whole[:3], half.download()[:3]):
+        assert np.array_equal(a.reshape(N, -1)[N // 2:], b.reshape(N, -1)[N // 2:])
+    assert small.stats().stack_overflows == 0
+    del small, half
+    # the hierarchy asked of the GPU builder (which hands a tree its stack bound rules out back to the host): same hits
+    pt.set_option("gpu_bvh_build", 1)
+    try:
+        t4 = time.perf_counter()
+        other = pt.DeviceScene(hs)
+        pt.sync()
+        t5 = time.perf_counter()
+    finally:
+        pt.set_option("gpu_bvh_build", 0)
+    other_info = other.build_info()
+    print(f"with gpu_bvh_build: ptk_scene_create {t5 - t4:.2f} s, {other_info['meshes_built_on_gpu']} mesh built on the GPU, "
+          f"{other_info['meshes_built_on_host']} on the host; build {other_info['bvh_build_wall_ms'] / 1e3:.2f} s by the host's clock, "
+          f"{other_info['bvh_build_ms']:.1f} ms {'of device time' if other_info['meshes_built_on_gpu'] else 'wall'}")
+    assert other_info["meshes_built_on_gpu"] + other_info["meshes_built_on_host"] == 1
+    rows = pt.make_job(500 * W, 8 * W, 1, 0, 31)
+    for a, b in zip(dev.trace_primary(rows), other.trace_primary(rows)):
+        assert np.array_equal(a, b)
+    assert other.stats().stack_overflows == 0
+    del other
+    # a run of pixels across the mesh against the oracle
+    t6 = time.perf_counter()
+    osc = ob.OracleScene(hs)
+    job = pt.make_job(560 * W + 800, 256, 2, 0, 31)
+    got, want = dev.trace_samples(job), osc.trace_samples(job)
+    print(f"oracle scene and 512 paths: {time.perf_counter() - t6:.1f} s")
+    ok = np.isclose(got[0].reshape(-1, 3), want[0].reshape(-1, 3), rtol=1e-9, atol=1e-12).all(axis=1)
+    assert ok.mean() >= 0.995, ok.mean()

@@ -146,6 +146,35 @@ def test_obj_transform_applies_only_with_a_center(tmp_path):
     np.testing.assert_allclose(v[0][1], [0, -2, -2], atol=1e-12)  # (2,-2,0) rotated 90 degrees about y
 
 
+def test_obj_parsed_in_parts_gives_the_same_triangles_and_the_first_error(tmp_path, monkeypatch):
+    """A generated mesh parsed whole and cut into 2, 7 and 64 parts (more parts than some sections have lines): identical
+    arrays.  With two bad lines in the file, the error is the one of the first bad line whichever part meets which."""
+    d = str(tmp_path / "mesh")
+    n = scenes.mesh_box(d, n_lon=48, n_lat=25, material="gold", WIDTH=16, HEIGHT=16)
+    def arrays():
+        hs = pt.load_scene_directory(d)
+        desc = hs.desc
+        assert desc.n_triangles == n
+        return [np.ctypeslib.as_array(a, shape=(n * k,)).copy() for a, k in ((desc.tri_vertices, 9), (desc.tri_uv, 6), (desc.tri_normals, 9))] + \
+               [np.ctypeslib.as_array(desc.tri_flags, shape=(n,)).copy()]
+    whole = arrays()
+    for parts in (2, 7, 64):
+        monkeypatch.setenv("PTK_OBJ_PARSE_PARTS", str(parts))
+        for a, b in zip(whole, arrays()):
+            assert np.array_equal(a, b), parts
+    path = os.path.join(d, "models", "bumpy_sphere.obj")
+    lines = open(path).read().split("\n")
+    vertex_lines = [i for i, l in enumerate(lines) if l.startswith("v ")]
+    lines[vertex_lines[10]] = "v first_bad 0 0"
+    lines[vertex_lines[-10]] = "v second_bad 0 0"
+    open(path, "w").write("\n".join(lines))
+    for parts in (1, 2, 7, 64):
+        monkeypatch.setenv("PTK_OBJ_PARSE_PARTS", str(parts))
+        with pytest.raises(pt.PtkError) as e:
+            pt.load_scene_directory(d)
+        assert "first_bad" in str(e.value), parts
+
+
 def test_obj_errors(tmp_path):
     with pytest.raises(pt.PtkError, match="Could not open file 'm2.obj'"):
         obj = {"name": "mesh", "type": "Object", "subtype": "ObjectUnion", "parameters": {"file": "m2.obj", "material": "m"}}
@@ -249,8 +278,13 @@ def loader_inputs(tmp_path_factory):
     return (d,) + loader_cases.write_inputs(d)
 
 
+@pytest.mark.parametrize("parts", [0, 5], ids=["whole", "in-5-parts"])
 @pytest.mark.parametrize("name,key,params", loader_cases.OBJ_CASES, ids=[c[0] for c in loader_cases.OBJ_CASES])
-def test_obj_loader_matches_the_reference_loader(loader_inputs, name, key, params):
+def test_obj_loader_matches_the_reference_loader(loader_inputs, monkeypatch, name, key, params, parts):
+    """parts = 5: the file is cut at line ends into five parts that are parsed on threads of their own and joined in
+    file order (what files of a megabyte or more get, one part per hardware thread); the result must not depend on it."""
+    if parts:
+        monkeypatch.setenv("PTK_OBJ_PARSE_PARTS", str(parts))
     directory, obj_paths, _ = loader_inputs
     golden = np.load(os.path.join(GOLDEN, "loader_obj.npz"))
     file = os.path.basename(obj_paths[key]) if key else "does_not_exist.obj"

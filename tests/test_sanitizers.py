@@ -11,10 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCRIPT = os.path.join(ROOT, "tools", "sanitize_host.sh")
 
 
-def test_multi_threaded_hierarchy_build_is_race_free_under_tsan():
+def test_multi_threaded_hierarchy_build_and_obj_parse_are_race_free_under_tsan():
     r = subprocess.run(["bash", SCRIPT, "thread"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "thread sanitizer: no report" in r.stdout and r.stdout.count("\nok ") + r.stdout.startswith("ok ") == 5
+    assert "loaded 8 9216" in r.stdout  # the mesh scene parsed in eight parts: 8 objects, 9216 triangles
 
 
 def test_fuzzed_scene_directories_load_cleanly_under_asan_and_ubsan():
