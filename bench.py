@@ -356,12 +356,16 @@ def run_workload(pt, args, ds, workload, width, height, spp, steps, warmup, code
         achieved = flops_per_launch / (ms_per_launch * 1e-3) / 1e12
         roofline = {"bound": "valu_f64", "kernel": kernel, "achieved": achieved, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / F64_PEAK_TFLOPS, "traffic": traffic}
+    elif traverse and "measured_GBps" in hbm:
+        # k_traverse against HBM, by what HBM delivered: the measured bytes per launch (rocprofv3 FETCH_SIZE x 2 +
+        # WRITE_SIZE) over the live launch time.  The algorithmic byte count is beside it (hbm.algorithmic_*): it
+        # includes node and triangle fetches that L2 and the Infinity Cache serve, so it flatters.
+        roofline = {"bound": "hbm", "kernel": kernel, "achieved": hbm["measured_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": hbm["measured_GBps"] / HBM_PEAK_GBS, "traffic": traffic, "basis": "measured HBM bytes per launch"}
     else:
-        # k_traverse (and k_bounce when no counter file is at hand): against HBM.  `achieved` is the algorithmic
-        # byte count, which for k_traverse includes node and triangle fetches the caches serve; the measured HBM
-        # bytes per launch are `traffic`, and hbm.measured_GBps is what HBM actually delivered
+        # no traffic measurement at hand (or k_bounce without a counter file): the algorithmic byte count against HBM
         roofline = {"bound": "hbm", "kernel": kernel, "achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": algorithmic_gbs / HBM_PEAK_GBS, "traffic": traffic}
+                    "frac": algorithmic_gbs / HBM_PEAK_GBS, "traffic": traffic, "basis": "algorithmic bytes per launch"}
     roofline.update({"hbm": hbm, "valu": valu, "ms_per_launch": ms_per_launch, "launches": int(d_launches),
                      "profiled_steps": profiled["steps"],
                      "device_ms": {"k_bounce": fam["k_bounce"][0], "k_bin": fam["k_bin"][0],
