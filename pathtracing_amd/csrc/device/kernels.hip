@@ -11,82 +11,132 @@ namespace ptk {
 // Exclusive scan, in class-major order, of block_counts[class * count_stride + chunk] over the
 // chunks of the pool `previous` describes, for every class in class_mask; one workgroup.  Leaves the offsets in place and the
 // per-class segment starts, counts and the total in `info`.  Tiles of 4096 counts: one uint4 per
-// thread, shuffles inside a wave, 16 wave sums through LDS, a running carry across tiles.
+// thread, shuffles inside a wave, 16 wave sums through LDS, a running carry across tiles; the counts of the next tile
+// (of this class or the next) are requested before the current ones are scanned, and the loop is kept small: the
+// kernel runs between two large ones and starts with a cold instruction cache.  Records only ever leave the pool: a
+// total above the previous one means the counts are corrupt, and the pool is declared empty rather than letting the
+// kernels behind this one index with them.
+// Inclusive prefix sum over the 64 lanes of a wave by data-parallel-primitive moves (no trip through LDS): shifts by
+// 1, 2, 4, 8 inside each row of 16 lanes (lanes without a source add 0), then the last lane of row 0 / 2 broadcast to
+// row 1 / 3, then the last lane of row 1 to rows 2 and 3.  Every lane of the wave must be active.
+PTK_DEV uint32_t wave_inclusive_sum(uint32_t x) {
+    int v = static_cast<int>(x);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false); // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false); // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false); // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false); // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); // row_bcast:31 into rows 2 and 3
+    return static_cast<uint32_t>(v);
+}
+
+PTK_DEV uint4 counts_at(const uint32_t* row, uint32_t at, uint32_t n) {
+    const uint32_t last = n ? (n - 1) & ~3u : 0; // the load stays inside the row (its stride is a multiple of four entries)
+    uint4 v = *reinterpret_cast<const uint4*>(row + min(at, last));
+    v.x = at < n ? v.x : 0;
+    v.y = at + 1 < n ? v.y : 0;
+    v.z = at + 2 < n ? v.z : 0;
+    v.w = at + 3 < n ? v.w : 0;
+    return v;
+}
+
 __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* block_counts, uint32_t count_stride, uint32_t class_mask, uint32_t rounds,
                                                    const BinInfo* previous, BinInfo* info) {
     const uint32_t n_blocks = chunk_table(previous, rounds * BLOCK).n_chunks;
     __shared__ uint32_t wave_sums[2][16];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t carry = 0; // the same in every thread
+    uint32_t carry = 0, class_start = 0; // the same in every thread
     int parity = 0;
-    for (int c = 0; c < N_CLASSES; c++) {
-        const uint32_t class_start = carry;
-        if ((class_mask >> c) & 1u) {
-            uint32_t* row = block_counts + static_cast<size_t>(c) * count_stride;
-            for (uint32_t base = 0; base < n_blocks; base += 4096) {
-                const uint32_t i = base + threadIdx.x * 4;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (i + 3 < n_blocks) v = *reinterpret_cast<const uint4*>(row + i);
-                else {
-                    if (i < n_blocks) v.x = row[i];
-                    if (i + 1 < n_blocks) v.y = row[i + 1];
-                    if (i + 2 < n_blocks) v.z = row[i + 2];
-                }
-                const uint32_t mine = v.x + v.y + v.z + v.w;
-                uint32_t incl = mine;
+    // (class, tile) pairs in order; classes outside the mask, and every class of an empty pool, have no tiles
+    const uint32_t tiles = (n_blocks + 4095) / 4096;
+    const uint32_t present = tiles ? class_mask & ((1u << N_CLASSES) - 1u) : 0u;
+    uint32_t left = present; // classes still to come, the current one included
+    uint32_t tile = 0;
+    uint4 next = make_uint4(0, 0, 0, 0);
+    if (left) next = counts_at(block_counts + static_cast<size_t>(__builtin_ctz(left)) * count_stride, threadIdx.x * 4, n_blocks);
+    while (left) {
+        const uint32_t c = __builtin_ctz(left);
+        const uint32_t i = tile * 4096 + threadIdx.x * 4;
+        uint32_t* row = block_counts + static_cast<size_t>(c) * count_stride;
+        const uint4 v = next;
+        const bool last_tile = tile + 1 == tiles;
+        if (last_tile) {
+            left &= left - 1;
+            tile = 0;
+        } else tile++;
+        if (left) next = counts_at(block_counts + static_cast<size_t>(__builtin_ctz(left)) * count_stride, tile * 4096 + threadIdx.x * 4, n_blocks);
+        const uint32_t mine = v.x + v.y + v.z + v.w;
+        const uint32_t incl = wave_inclusive_sum(mine);
+        if (lane == 63) wave_sums[parity][wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, tile_total = 0;
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    uint32_t up = __shfl_up(incl, off);
-                    if (lane >= static_cast<uint32_t>(off)) incl += up;
-                }
-                if (lane == 63) wave_sums[parity][wave] = incl;
-                __syncthreads();
-                uint32_t before = 0, tile_total = 0;
-#pragma unroll
-                for (uint32_t w = 0; w < 16; w++) {
-                    uint32_t sum = wave_sums[parity][w];
-                    if (w < wave) before += sum;
-                    tile_total += sum;
-                }
-                parity ^= 1; // the other buffer is free: every wave passed the barrier after reading it
-                uint32_t e = carry + before + incl - mine;
-                uint4 o;
-                o.x = e;
-                o.y = e + v.x;
-                o.z = o.y + v.y;
-                o.w = o.z + v.z;
-                if (i + 3 < n_blocks) *reinterpret_cast<uint4*>(row + i) = o;
-                else {
-                    if (i < n_blocks) row[i] = o.x;
-                    if (i + 1 < n_blocks) row[i + 1] = o.y;
-                    if (i + 2 < n_blocks) row[i + 2] = o.z;
-                }
-                carry += tile_total;
-            }
+        for (uint32_t w = 0; w < 16; w++) {
+            uint32_t sum = wave_sums[parity][w];
+            if (w < wave) before += sum;
+            tile_total += sum;
         }
-        if (threadIdx.x == 0) {
-            info->start[c] = class_start;
-            info->count[c] = carry - class_start;
+        parity ^= 1; // the other buffer is free: every wave passed the barrier after reading it
+        uint32_t e = carry + before + incl - mine;
+        uint4 o;
+        o.x = e;
+        o.y = e + v.x;
+        o.z = o.y + v.y;
+        o.w = o.z + v.z;
+        if (i + 3 < n_blocks) *reinterpret_cast<uint4*>(row + i) = o;
+        else { // the last, partial group; entries past the last chunk stay as they are (zero)
+            if (i < n_blocks) row[i] = o.x;
+            if (i + 1 < n_blocks) row[i + 1] = o.y;
+            if (i + 2 < n_blocks) row[i + 2] = o.z;
+        }
+        carry += tile_total;
+        if (last_tile) {
+            if (threadIdx.x == 0) {
+                info->start[c] = class_start;
+                info->count[c] = carry - class_start;
+            }
+            class_start = carry;
         }
     }
     if (threadIdx.x == 0) {
-        info->total = carry;
+        const bool sane = carry <= previous->total;
+        // classes without tiles: empty segments where they belong in the order (ascending starts)
+        uint32_t start = 0;
+        for (int c = 0; c < N_CLASSES; c++) {
+            if ((present >> c) & 1u) {
+                if (!sane) info->count[c] = 0;
+                start = info->start[c] + info->count[c];
+            } else {
+                info->start[c] = start;
+                info->count[c] = 0;
+            }
+        }
+        info->total = sane ? carry : 0;
         info->cursor = 0;
     }
 }
 
 // Writes the class-sorted index list: a record that continues with class c goes to
 // block_offsets[c][chunk] + (number of class-c records before it in its chunk).  Records of paths
-// that ended are left out.  One block per chunk of the pool `previous` describes.
-__global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathPool pool, const BinInfo* previous, const uint32_t* block_offsets,
+// that ended are left out.  One block per chunk of the pool `previous` describes.  The block is the only reader of its
+// chunk's offsets and leaves zeros there: the next bounce adds its class counts to them (add_chunk_counts).
+__global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathPool pool, const BinInfo* previous, uint32_t* block_offsets,
                                                        uint32_t count_stride, uint32_t class_mask, uint32_t rounds, uint32_t* list_out) {
     const ChunkTable table = chunk_table(previous, rounds * BLOCK);
     if (blockIdx.x >= table.n_chunks) return;
+    const uint32_t capacity = previous->total; // the list is no longer than the pool it sorts; nothing is written past that
     int chunk_class;
     uint32_t first, n;
     locate_chunk(table, rounds * BLOCK, blockIdx.x, chunk_class, first, n);
     __shared__ uint32_t counts[BIN_ROUNDS][BLOCK / 64][N_CLASSES];
     const int wave = threadIdx.x >> 6;
+    // the chunk's offsets are asked for first, so that they arrive while the classes are read and counted
+    const bool owns_class = threadIdx.x < N_CLASSES && ((class_mask >> threadIdx.x) & 1u);
+    uint32_t chunk_offset = 0;
+    if (owns_class) {
+        chunk_offset = block_offsets[threadIdx.x * count_stride + blockIdx.x];
+        block_offsets[threadIdx.x * count_stride + blockIdx.x] = 0;
+    }
     int classes[BIN_ROUNDS];
     uint32_t below[BIN_ROUNDS];
 #pragma unroll
@@ -109,8 +159,8 @@ __global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathPool pool, const BinI
     }
     __syncthreads();
     // exclusive prefix over (round, wave) for each class, plus the chunk's global offset
-    if (threadIdx.x < N_CLASSES && ((class_mask >> threadIdx.x) & 1u)) {
-        uint32_t running = block_offsets[threadIdx.x * count_stride + blockIdx.x];
+    if (owns_class) {
+        uint32_t running = chunk_offset;
         for (int r = 0; r < BIN_ROUNDS; r++)
             for (int w = 0; w < BLOCK / 64; w++) {
                 uint32_t v = counts[r][w][threadIdx.x];
@@ -121,7 +171,10 @@ __global__ __launch_bounds__(BLOCK) void k_bin_scatter(PathPool pool, const BinI
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < BIN_ROUNDS; r++)
-        if (classes[r] >= 0) list_out[counts[r][wave][classes[r]] + below[r]] = first + r * BLOCK + threadIdx.x;
+        if (classes[r] >= 0) {
+            const uint32_t place = counts[r][wave][classes[r]] + below[r];
+            if (place < capacity) list_out[place] = first + r * BLOCK + threadIdx.x;
+        }
 }
 
 // Completes the records of the camera rays that waited for k_traverse: where the ray ends (the closest hit of the
@@ -444,20 +497,27 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(PTK_TRAVERSE_QUAD_WAVES) 
     add_block_statistics(statistics, wave_sums, stat);
 }
 
-// Sums the per-block statistics slots into totals[N_STATISTICS]; one block.
+// Adds the per-block statistics slots to totals[N_STATISTICS] (zero before): one slot (64 bytes) per thread, a
+// reduction inside each wave, one atomic per wave and value.
 __global__ __launch_bounds__(BLOCK) void k_sum_statistics(const unsigned long long* slots, unsigned long long* totals) {
-    __shared__ unsigned long long partial[BLOCK];
+    static_assert(N_STATISTICS == 8 && STATISTICS_SLOTS % BLOCK == 0, "a slot is read as four pairs, one slot per thread");
+    const ulonglong2* slot = reinterpret_cast<const ulonglong2*>(slots + static_cast<size_t>(blockIdx.x * BLOCK + threadIdx.x) * N_STATISTICS);
+    unsigned long long sum[N_STATISTICS];
+#pragma unroll
+    for (int k = 0; k < N_STATISTICS / 2; k++) {
+        const ulonglong2 v = slot[k];
+        sum[2 * k] = v.x;
+        sum[2 * k + 1] = v.y;
+    }
+#pragma unroll
     for (int k = 0; k < N_STATISTICS; k++) {
-        unsigned long long sum = 0;
-        for (int s = threadIdx.x; s < STATISTICS_SLOTS; s += BLOCK) sum += slots[static_cast<size_t>(s) * N_STATISTICS + k];
-        partial[threadIdx.x] = sum;
-        __syncthreads();
-        for (int off = BLOCK / 2; off > 0; off >>= 1) {
-            if (threadIdx.x < off) partial[threadIdx.x] += partial[threadIdx.x + off];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) totals[k] = partial[0];
-        __syncthreads();
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum[k] += __shfl_down(sum[k], off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < N_STATISTICS; k++)
+            if (sum[k]) atomicAdd(totals + k, sum[k]);
     }
 }
 
@@ -697,9 +757,7 @@ void launch_bounce(const LaunchContext& lc, uint32_t bound, uint32_t rounds, con
     const hipStream_t s = lc.stream;
     const dim3 grid(min(chunk_blocks(bound, rounds), static_cast<uint32_t>(STATISTICS_SLOTS)));
     const Variant v = variant_of(sc, lc.specialised);
-    // the kernels that finish every vertex themselves add their class counts to zeros (add_chunk_counts); an error of
-    // the call is the stream's last error, which the caller checks after the launch
-    if (!v.defer) (void) hipMemset2DAsync(block_counts, count_stride * sizeof(uint32_t), 0, chunk_blocks(bound, rounds) * sizeof(uint32_t), N_CLASSES, s);
+    // the kernels that finish every vertex themselves add their class counts to the zeros k_bin_scatter left (add_chunk_counts)
 #define PTK_CASE(T, U, D, P, C)                                                                                                    \
     if (v.tris == T && v.uv == U && v.defer == D && v.pass == P && v.cache == C)                                                   \
         return launch_bounce_variant<T, U, D, P, C>(s, grid, sc, b, in, out, res, list, info, rounds, block_counts, count_stride, \
@@ -782,7 +840,7 @@ void launch_count_classes(const LaunchContext& lc, uint32_t bound, uint32_t roun
 }
 
 void launch_sum_statistics(hipStream_t s, const unsigned long long* slots, unsigned long long* totals) {
-    hipLaunchKernelGGL(k_sum_statistics, dim3(1), dim3(BLOCK), 0, s, slots, totals);
+    hipLaunchKernelGGL(k_sum_statistics, dim3(STATISTICS_SLOTS / BLOCK), dim3(BLOCK), 0, s, slots, totals);
 }
 
 void launch_accumulate(hipStream_t s, const BatchParams& b, const SampleResults& res, double* image, double* position, double* normal,

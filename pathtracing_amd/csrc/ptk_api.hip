@@ -526,6 +526,8 @@ int trace_batch(PtkScene* s, BatchLane& lane, const BatchParams& b) {
     const uint32_t tail_records = g_tail_records.load();
     const int launch_ahead = g_launch_ahead.load();
     HIP_TRY(hipMemsetAsync(lane.d_statistics, 0, STATISTICS_BYTES, g_stream));
+    // the class counts start at zero once per batch; from then on every class sort leaves zeros where it read offsets
+    HIP_TRY(hipMemsetAsync(lane.block_counts, 0, static_cast<size_t>(lane.count_stride) * N_CLASSES * sizeof(uint32_t), g_stream));
     if (s->dev.has_meshes) HIP_TRY(hipMemsetAsync(lane.queues.counters, 0, 4 * sizeof(uint32_t), g_stream));
     timer.begin(2);
     launch_generate(g_stream, s->dev, b, lane.pools[0], lane.results, &lane.d_info[1], lane.block_counts, lane.count_stride, lane.queues);

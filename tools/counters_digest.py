@@ -26,15 +26,21 @@ def main():
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     dur = collections.defaultdict(float)
     seen = collections.defaultdict(set)
+    per_pass = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+    pass_dur = collections.defaultdict(lambda: collections.defaultdict(float))
+    first_pass_of = {}
     for path in paths:
         for r in csv.DictReader(open(path)):
             k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").strip()
             if k.startswith("__amd"):
                 continue
-            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            per_pass[k][path][r["Counter_Name"]] += float(r["Counter_Value"])
+            if first_pass_of.setdefault(r["Counter_Name"], path) == path:  # a counter collected in two passes counts once
+                agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             key = (path, r["Dispatch_Id"])
             if key not in seen[k]:
                 seen[k].add(key)
+                pass_dur[k][path] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
                 if path == paths[0]:
                     dur[k] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     rows, latest = [], {}
@@ -62,6 +68,16 @@ def main():
             entry["active_lanes_per_valu"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]
         if wave_cycles and c.get("SQ_WAIT_INST_ANY"):
             entry["wait_share_of_wave_time"] = c["SQ_WAIT_INST_ANY"] / wave_cycles
+        # the third pass has its own SQ_WAVE_CYCLES (agg sums passes, so use the per-pass figures kept below)
+        third = per_pass[k][paths[-1]] if len(paths) > 2 else {}
+        if third.get("SQ_WAVE_CYCLES"):
+            for name, key in (("SQ_WAIT_ANY", "any_wait_share"), ("SQ_ACTIVE_INST_ANY", "issue_share"),
+                              ("SQ_ACTIVE_INST_VMEM", "vmem_issue_share"), ("SQ_ACTIVE_INST_LDS", "lds_issue_share"),
+                              ("SQ_ACTIVE_INST_SCA", "scalar_issue_share")):
+                if name in third:
+                    entry[key] = third[name] / third["SQ_WAVE_CYCLES"]
+            if third.get("GRBM_GUI_ACTIVE") and pass_dur[k].get(paths[-1]):
+                entry["clock_ghz"] = third["GRBM_GUI_ACTIVE"] / pass_dur[k][paths[-1]]  # cycles per nanosecond
         for name in ("ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64", "INT32", "INT64"):
             v = c.get("SQ_INSTS_VALU_" + name)
             if v:
@@ -76,17 +92,21 @@ def main():
     json.dump(data, open(js, "w"), indent=1, sort_keys=True)
     with open(os.path.join(out_dir, f"{rnd}_{workload}_counters.md"), "w") as f:
         f.write(f"# SQ counters per kernel, workload `{workload}` ({rnd})\n\n")
-        f.write("rocprofv3 `--pmc`, one pass per counter group (`tools/pmc_pass.sh`), `bench.py --steps 1 --warmup 1`.\n")
+        f.write("rocprofv3 `--pmc`, one pass per counter group (`tools/pmc_pass.sh`), `bench.py --steps 1 --warmup 1 --spp-per-step 8`.\n")
         f.write("`VALU share` = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES: the part of a wave's life spent issuing vector\n")
         f.write("instructions; times the waves per SIMD the kernel is compiled for it is the share of the SIMD's issue\n")
-        f.write("slots in use.  `lanes` = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU: active lanes per vector instruction.\n\n")
-        f.write("| kernel | waves | VALU/wave | SALU/wave | VALU share | wait share | lanes | fma/mul/add/trans f64, int32, int64 per wave |\n|---|---|---|---|---|---|---|---|\n")
+        f.write("slots in use.  `lanes` = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU: active lanes per vector instruction.\n")
+        f.write("`any wait` = SQ_WAIT_ANY / SQ_WAVE_CYCLES, `issuing` = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES and the per-pipe issue\n")
+        f.write("shares come from a third pass; `clock` = GRBM_GUI_ACTIVE over the kernel's duration in that pass.\n\n")
+        f.write("| kernel | waves | VALU/wave | SALU/wave | VALU share | wait share | lanes | fma/mul/add/trans f64, int32, int64 per wave | any wait | issuing | vmem / lds / scalar issue | clock GHz |\n|---|---|---|---|---|---|---|---|---|---|---|---|\n")
         for k, e in rows:
             mix = "/".join(f"{e.get(n + '_per_wave', 0):.0f}" for n in ("fma_f64", "mul_f64", "add_f64", "trans_f64")) + \
                   f", {e.get('int32_per_wave', 0):.0f}, {e.get('int64_per_wave', 0):.0f}"
             f.write(f"| `{k}` | {e['waves']:.0f} | {e.get('valu_per_wave', 0):.0f} | {e.get('salu_per_wave', 0):.0f} | "
                     f"{100 * e.get('valu_share_of_wave_time', 0):.1f} % | {100 * e.get('wait_share_of_wave_time', 0):.1f} % | "
-                    f"{e.get('active_lanes_per_valu', 0):.1f} | {mix} |\n")
+                    f"{e.get('active_lanes_per_valu', 0):.1f} | {mix} | {100 * e.get('any_wait_share', 0):.1f} % | "
+                    f"{100 * e.get('issue_share', 0):.1f} % | {100 * e.get('vmem_issue_share', 0):.1f} / "
+                    f"{100 * e.get('lds_issue_share', 0):.1f} / {100 * e.get('scalar_issue_share', 0):.1f} % | {e.get('clock_ghz', 0):.2f} |\n")
     print("wrote", out_dir)
 
 

@@ -74,7 +74,8 @@ def main():
         json.dump(data, f, indent=1, sort_keys=True)
     with open(os.path.join(out_dir, f"{rnd}_{workload}_traffic.md"), "w") as f:
         f.write(f"# HBM traffic per launch, workload `{workload}` ({rnd})\n\n")
-        f.write("rocprofv3 `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, one pass each, `bench.py --steps 2 --warmup 1`.\n")
+        command = "tools/denoise_bench.py 2" if workload == "denoise" else "bench.py --steps 2 --warmup 1 --spp-per-step 8"
+        f.write(f"rocprofv3 `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, one pass each, `{command}`.\n")
         f.write("Counter unit: kilobytes.  Reads = 2 x FETCH_SIZE (gfx950 tallies the 128-byte requests of 16-byte-per-lane\n")
         f.write("streaming reads as 64 bytes); writes = WRITE_SIZE.  Averages over all launches of the kernel in the run.\n\n")
         f.write("| kernel | launches | read MB/launch | write MB/launch | total MB/launch |\n|---|---|---|---|---|\n")
