@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="example", choices=["example", "mesh", "cloud", "room"])
+    ap.add_argument("--workload", default="example", choices=["example", "mesh", "cloud", "room", "example_deferred"])
     ap.add_argument("--partition", default="samples", choices=["samples", "tiles"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -98,6 +98,9 @@ def build_workload(args, workload, directory, width, height, spp, steps):
     if workload == "example":
         scenes.cornell_example(directory, **settings)
         return "scenes/example Cornell box (12 analytic objects)"
+    if workload == "example_deferred":
+        scenes.cornell_example_all_deferred(directory, **settings)
+        return "scenes/example with every vertex sent through the deferred route (a two-triangle mesh whose bounds hold the room)"
     if workload == "mesh":
         n = scenes.mesh_box(directory, n_lon=args.mesh_lon, n_lat=args.mesh_lat, material="gold", smooth=True, **settings)
         return f"Cornell walls + generated {n}-triangle OBJ mesh (MetallicMicrofacet)"
@@ -226,8 +229,8 @@ def run_workload(pt, args, ds, workload, width, height, spp, steps, warmup, code
     W, H = width, frame_height
     n_pixels = W * H
     band_start, own_pixels, band_pixels, band_stride = band_job(rank, world, W, H, band_rows=8) if tiles else (0, n_pixels, 0, 0)
-    # at most 2^24 paths in flight: a step of more samples per pixel is traced as several batches of whole pixels
-    scene = pt.DeviceScene(host_scene, max_paths_in_flight=max(min(width * height * spp, 1 << 24), 1 << 22))
+    # at most 2^25 paths in flight: a step of more than 2^24 paths is traced as batches of whole pixels, two at a time
+    scene = pt.DeviceScene(host_scene, max_paths_in_flight=max(min(width * height * spp, 1 << 25), 1 << 22))
     build_s = time.perf_counter() - t_build
 
     combiner = None

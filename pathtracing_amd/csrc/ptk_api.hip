@@ -239,7 +239,11 @@ struct DeviceBuffers {
     }
 };
 
-constexpr int64_t DEFAULT_MAX_PATHS = int64_t(1) << 24;
+// Paths of one batch: the kernels address a record by a 32-bit byte offset into its pool (160 bytes per record).
+constexpr int64_t BATCH_MAX_PATHS = int64_t(1) << 24;
+static_assert(BATCH_MAX_PATHS * 160 <= (int64_t(1) << 32), "record offsets are 32-bit");
+constexpr int64_t DEFAULT_MAX_PATHS = BATCH_MAX_PATHS;  // paths in flight of a scene created without a limit of its own
+constexpr int64_t MAX_PATHS_LIMIT = 2 * BATCH_MAX_PATHS; // two batches of the largest size, one per lane
 constexpr int INFO_RING = 8;
 
 // What one batch in flight needs.  A scene has two lanes: a large job is cut into batches of half the paths-in-flight
@@ -671,7 +675,7 @@ int check_job(const PtkScene* s, const PtkRenderJob* job, const char* who) {
     if (job->start_idx < 0 || job->number_of_pixels < 0 || job->start_idx + job->number_of_pixels > n)
         return fail(PTK_ERR_INVALID, std::string(who) + ": pixel range outside the image");
     if (job->number_of_samples < 0 || job->sample_offset < 0) return fail(PTK_ERR_INVALID, std::string(who) + ": negative sample count");
-    if (job->number_of_samples > s->max_paths)
+    if (job->number_of_samples > std::min(s->max_paths, BATCH_MAX_PATHS))
         return fail(PTK_ERR_MEMORY, std::string(who) + ": number_of_samples exceeds the paths-in-flight limit");
     return PTK_OK;
 }
@@ -707,17 +711,24 @@ void add_stats(PtkStats& total, const PtkStats& part) {
 // Jobs of TWO_LANE_PATHS paths or more go through both lanes, two batches at a time, in scenes with meshes (option
 // batch_lanes; measured on one MI355X, 1080p, 8 samples per pixel per job: +4 % on the 1M-triangle mesh and on the room, whose
 // hierarchy walks end in a few long rays that leave most of the device idle; nothing on the Cornell scene, -2 % on the
-// cloud).  Every batch covers pixels of its own, so the order in which batches finish does not show in the results.
+// cloud) and, in every scene, for jobs that take more than one batch.  Every batch covers pixels of its own, so the order in which batches finish does not show in the results.
 constexpr int64_t TWO_LANE_PATHS = int64_t(1) << 21;
 template<typename F>
 int for_each_batch(PtkScene* s, const PtkRenderJob* job, F&& after_batch, uint32_t band_pixels = 0, uint32_t band_stride = 0) {
     if (job->number_of_pixels == 0 || job->number_of_samples == 0) return PTK_OK;
     const int64_t job_paths = job->number_of_pixels * job->number_of_samples;
     const int wanted = g_batch_lanes.load();
-    const bool two = wanted == 2 || (wanted == 0 && s->dev.has_meshes);
+    // two lanes: where asked for; in scenes with meshes; and for a job that takes several batches anyway (the lanes then
+    // trace batches of the size one lane would, and the short kernels at the end of one batch run beside the large ones
+    // of the other)
+    const int64_t one_lane_batch = std::min(s->max_paths, BATCH_MAX_PATHS);
+    const bool two = wanted == 2 || (wanted == 0 && (s->dev.has_meshes || job_paths > one_lane_batch));
     const int n_lanes = two && job->number_of_pixels >= 2 && job_paths >= TWO_LANE_PATHS && 2 * job->number_of_samples <= s->max_paths ? 2 : 1;
-    const int64_t per_batch = std::max<int64_t>(1, s->max_paths / n_lanes / job->number_of_samples);
-    const int64_t batch_pixels = std::min<int64_t>(per_batch, (job->number_of_pixels + n_lanes - 1) / n_lanes);
+    const int64_t per_batch = std::max<int64_t>(1, std::min(s->max_paths / n_lanes, BATCH_MAX_PATHS) / job->number_of_samples);
+    // batches of equal size, as many for one lane as for the other
+    int64_t n_batches = (job->number_of_pixels + per_batch - 1) / per_batch;
+    n_batches = (n_batches + n_lanes - 1) / n_lanes * n_lanes;
+    const int64_t batch_pixels = (job->number_of_pixels + n_batches - 1) / n_batches;
     std::vector<BatchParams> batches;
     std::vector<int64_t> first_pixel;
     for (int64_t p = 0; p < job->number_of_pixels; p += batch_pixels) {
@@ -932,7 +943,7 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     s->settings = d->settings;
     // records are addressed with 32-bit byte offsets (160 bytes each): at most 2^24 in flight; larger jobs are
     // cut into batches anyway
-    s->max_paths = max_paths_in_flight > 0 ? std::min(max_paths_in_flight, DEFAULT_MAX_PATHS) : DEFAULT_MAX_PATHS;
+    s->max_paths = max_paths_in_flight > 0 ? std::min(max_paths_in_flight, MAX_PATHS_LIMIT) : DEFAULT_MAX_PATHS;
     DevScene& dev = s->dev;
     DeviceBuffers& buf = s->scene_buffers;
 

@@ -150,6 +150,23 @@ def cornell_example(directory, **settings):
 # ------------------------------------------------------------------------------------------
 # textures and meshes
 # ------------------------------------------------------------------------------------------
+def cornell_example_all_deferred(directory, **settings):
+    """The example box plus a mesh of two specks outside opposite corners of the room, so that the bounds of the mesh
+    hold the whole scene: every ray enters them, and every vertex takes the deferred route (shading kernel -> ray queue
+    -> traversal kernel -> completion kernel).  The image is the example's; the scene measures what that route costs
+    when the walk itself is free."""
+    os.makedirs(os.path.join(directory, "models"), exist_ok=True)
+    with open(os.path.join(directory, "models", "specks.obj"), "w") as f:
+        for x, y, z in ((-1.15, -0.05, -2.05), (1.15, 2.05, 2.05)):
+            f.write(f"v {x} {y} {z}\nv {x + 1e-3} {y} {z}\nv {x} {y + 1e-3} {z}\n")
+        f.write("f 1 2 3\nf 4 5 6\n")
+    scene = cornell_example_dict()
+    scene["objects"] = scene["objects"] + [{"name": "specks", "type": "Object", "subtype": "ObjectUnion",
+                                            "parameters": {"file": "models/specks.obj", "material": "white_diffuse_material",
+                                                           "enable_smooth_shading": False}}]
+    return write_scene_directory(directory, scene, default_settings(**settings))
+
+
 def write_map_file(path, data):
     """`.map`: float64 [width, height, dim, data...] with data row-major [h][w][dim]."""
     a = np.ascontiguousarray(data, dtype=np.float64)

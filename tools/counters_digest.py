@@ -31,7 +31,7 @@ def main():
     first_pass_of = {}
     for path in paths:
         for r in csv.DictReader(open(path)):
-            k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").strip()
+            k = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "").strip()
             if k.startswith("__amd"):
                 continue
             per_pass[k][path][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -77,7 +77,7 @@ def main():
                 if name in third:
                     entry[key] = third[name] / third["SQ_WAVE_CYCLES"]
             if third.get("GRBM_GUI_ACTIVE") and pass_dur[k].get(paths[-1]):
-                entry["clock_ghz"] = third["GRBM_GUI_ACTIVE"] / pass_dur[k][paths[-1]]  # cycles per nanosecond
+                entry["clock_ghz"] = third["GRBM_GUI_ACTIVE"] / 8.0 / pass_dur[k][paths[-1]]  # summed over the 8 XCDs; cycles per nanosecond
         for name in ("ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64", "INT32", "INT64"):
             v = c.get("SQ_INSTS_VALU_" + name)
             if v:
@@ -92,7 +92,8 @@ def main():
     json.dump(data, open(js, "w"), indent=1, sort_keys=True)
     with open(os.path.join(out_dir, f"{rnd}_{workload}_counters.md"), "w") as f:
         f.write(f"# SQ counters per kernel, workload `{workload}` ({rnd})\n\n")
-        f.write("rocprofv3 `--pmc`, one pass per counter group (`tools/pmc_pass.sh`), `bench.py --steps 1 --warmup 1 --spp-per-step 8`.\n")
+        command = "tools/denoise_bench.py 2" if workload == "denoise" else "bench.py --steps 1 --warmup 1 --spp-per-step 8"
+        f.write(f"rocprofv3 `--pmc`, one pass per counter group (`tools/profile_round.sh`, `tools/profile_all.sh`), `{command}`.\n")
         f.write("`VALU share` = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES: the part of a wave's life spent issuing vector\n")
         f.write("instructions; times the waves per SIMD the kernel is compiled for it is the share of the SIMD's issue\n")
         f.write("slots in use.  `lanes` = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU: active lanes per vector instruction.\n")

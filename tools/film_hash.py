@@ -1,6 +1,9 @@
-"""Prints a hash of the film a device-library build renders for a fixed set of scenes and jobs, one line per scene.
-Two builds whose lines agree render the same films bit for bit: the check behind every change to the kernels that is
-meant to cost less without changing a result (select the build with PTK_DEVICE_LIBRARY, as for bench.py).
+"""Prints hashes of the film a device-library build renders for a fixed set of scenes and jobs, one line per scene:
+first with the default switch to the tail kernel (a frame this small is traced by k_generate and k_tail alone), then
+with tail_records = 0, which sends the same job through the class sort and k_bounce (with k_traverse and
+k_bounce_resume in scenes with meshes) as a full-size frame is.  Two builds whose lines agree render the same films
+bit for bit: the check behind every change to the kernels that is meant to cost less without changing a result
+(select the build with PTK_DEVICE_LIBRARY, as for bench.py).
 usage: python tools/film_hash.py [first_random_seed last_random_seed]"""
 import hashlib
 import os
@@ -49,7 +52,11 @@ def main():
             host_scene = pt.load_scene_directory(directory)
         finally:
             shutil.rmtree(directory, ignore_errors=True)
-        print(name, film_hash(host_scene, 11), flush=True)
+        pt.set_option("tail_records", 1048576)
+        by_tail = film_hash(host_scene, 11)
+        pt.set_option("tail_records", 0)
+        by_bounces = film_hash(host_scene, 11)
+        print(name, by_tail, by_bounces, flush=True)
 
 
 if __name__ == "__main__":

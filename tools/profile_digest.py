@@ -25,7 +25,7 @@ from bench import sources_hash  # noqa: E402
 
 
 def kernel_name(raw):
-    name = re.sub(r"\(.*", "", raw).replace("void ", "")
+    name = re.sub(r"\(.*", "", raw.replace("(anonymous namespace)::", "")).replace("void ", "")
     return name.strip()
 
 
