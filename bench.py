@@ -229,8 +229,10 @@ def run_workload(pt, args, ds, workload, width, height, spp, steps, warmup, code
     W, H = width, frame_height
     n_pixels = W * H
     band_start, own_pixels, band_pixels, band_stride = band_job(rank, world, W, H, band_rows=8) if tiles else (0, n_pixels, 0, 0)
-    # at most 2^25 paths in flight: a step of more than 2^24 paths is traced as batches of whole pixels, two at a time
-    scene = pt.DeviceScene(host_scene, max_paths_in_flight=max(min(width * height * spp, 1 << 25), 1 << 22))
+    # a step of more than 2^24 paths is traced as batches of whole pixels, several at a time (option batch_lanes), each of
+    # at most 2^24 paths
+    lanes = max(int(dict(o.split("=", 1) for o in args.option).get("batch_lanes", 0)), 2)
+    scene = pt.DeviceScene(host_scene, max_paths_in_flight=max(min(width * height * spp, lanes << 24), 1 << 22))
     build_s = time.perf_counter() - t_build
 
     combiner = None

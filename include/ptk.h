@@ -222,8 +222,8 @@ void* ptk_stream(void);
 /* Replaces Scene construction (src/scene.cpp:546-584) as seen by the render loop:
  * copies the description to the device, builds the mesh acceleration structure
  * (replaces BVH::Node::Node, src/bvh.cpp:129-165) and sizes the path pools.
- * `max_paths_in_flight` <= 0 selects the default (2^24); at most 2^25 is used: a job larger than a batch
- * (2^24 paths at most) is traced as batches of whole pixels, two at a time when it takes several (option
+ * `max_paths_in_flight` <= 0 selects the default (2^24); at most 2^26 is used: a job larger than a batch
+ * (2^24 paths at most) is traced as batches of whole pixels, two or more at a time when it takes several (option
  * batch_lanes).  The caller may free every array of `desc` on return. */
 int ptk_scene_create(const PtkSceneDesc* desc, int64_t max_paths_in_flight, PtkScene** out);
 void ptk_scene_destroy(PtkScene* scene);
@@ -322,9 +322,10 @@ int ptk_set_profiling(int enabled);
  *     nor above four times it; a batch of no more paths than this value switches at this value in every scene.
  *   "launch_ahead": 0 to 7 (default 7), the bounces the host queues beyond the newest record count it has read back;
  *     fewer makes the switch to the tail kernel prompt and leaves the device waiting for the host between bounces.
- *   "batch_lanes": 1 traces the batches of a job one after the other; 2 cuts jobs of 2^21 paths or more into
- *     batches of half the paths-in-flight limit and traces two at a time, each on a stream and a host thread of its
- *     own; 0 (default) does that for scenes with meshes only.
+ *   "batch_lanes": 1 traces the batches of a job one after the other; n = 2 to 4 cuts jobs of 2^21 paths or more into
+ *     batches of 1/n of the paths-in-flight limit (2^24 paths at most) and traces n at a time, each on a stream and a
+ *     host thread of its own; 0 (default) traces two at a time in scenes with meshes and wherever a job takes more
+ *     than one batch anyway.
  *   "gpu_bvh_build": 1 builds the hierarchy of every mesh of 1024 triangles or more on the GPU when the next scenes
  *     are created (a linear BVH over Morton-ordered triangles: built in milliseconds, costlier to walk than the
  *     host's surface-area tree); 0 (default) builds on the host.  A mesh whose build the device has no memory for

@@ -243,7 +243,8 @@ struct DeviceBuffers {
 constexpr int64_t BATCH_MAX_PATHS = int64_t(1) << 24;
 static_assert(BATCH_MAX_PATHS * 160 <= (int64_t(1) << 32), "record offsets are 32-bit");
 constexpr int64_t DEFAULT_MAX_PATHS = BATCH_MAX_PATHS;  // paths in flight of a scene created without a limit of its own
-constexpr int64_t MAX_PATHS_LIMIT = 2 * BATCH_MAX_PATHS; // two batches of the largest size, one per lane
+constexpr int MAX_LANES = 4;                              // batches in flight at a time, at most
+constexpr int64_t MAX_PATHS_LIMIT = MAX_LANES * BATCH_MAX_PATHS; // a batch of the largest size in every lane
 constexpr int INFO_RING = 8;
 
 // What one batch in flight needs.  A scene has two lanes: a large job is cut into batches of half the paths-in-flight
@@ -354,10 +355,10 @@ struct PtkScene {
     PtkSettings settings{};
     DeviceBuffers scene_buffers; // tables, triangles, nodes
     int64_t max_paths = DEFAULT_MAX_PATHS;
-    BatchLane lanes[2];
+    BatchLane lanes[MAX_LANES];
     std::vector<int> classes; // queue classes present in the scene
     PtkFilm* host_film = nullptr; // scratch film for ptk_render_host
-    std::unique_ptr<LaneWorker> worker; // the second lane's host thread, from the first two-lane job on
+    std::unique_ptr<LaneWorker> workers[MAX_LANES - 1]; // the host threads of the lanes after the first, each from the first job that uses it on
     PtkStats stats{};
     double bvh_build_ms = 0;      // hierarchy builds of all meshes: device time (GPU build) or wall time (host build)
     double bvh_build_wall_ms = 0; // the same builds by the host's clock: allocations, copies, waits and the stack bound included
@@ -722,8 +723,9 @@ int for_each_batch(PtkScene* s, const PtkRenderJob* job, F&& after_batch, uint32
     // trace batches of the size one lane would, and the short kernels at the end of one batch run beside the large ones
     // of the other)
     const int64_t one_lane_batch = std::min(s->max_paths, BATCH_MAX_PATHS);
-    const bool two = wanted == 2 || (wanted == 0 && (s->dev.has_meshes || job_paths > one_lane_batch));
-    const int n_lanes = two && job->number_of_pixels >= 2 && job_paths >= TWO_LANE_PATHS && 2 * job->number_of_samples <= s->max_paths ? 2 : 1;
+    int n_lanes = wanted > 0 ? wanted : (s->dev.has_meshes || job_paths > one_lane_batch) ? 2 : 1;
+    if (job_paths < TWO_LANE_PATHS) n_lanes = 1;
+    while (n_lanes > 1 && (job->number_of_pixels < n_lanes || n_lanes * job->number_of_samples > s->max_paths)) n_lanes--;
     const int64_t per_batch = std::max<int64_t>(1, std::min(s->max_paths / n_lanes, BATCH_MAX_PATHS) / job->number_of_samples);
     // batches of equal size, as many for one lane as for the other
     int64_t n_batches = (job->number_of_pixels + per_batch - 1) / per_batch;
@@ -761,45 +763,51 @@ int for_each_batch(PtkScene* s, const PtkRenderJob* job, F&& after_batch, uint32
     };
     if (n_lanes == 1) rc = run_lane(0);
     else {
-        BatchLane& other = s->lanes[1];
-        // the other lane's stream begins after what the context's stream holds so far (a film cleared or uploaded), and the
-        // context's stream goes on after the other lane's work
-        hipError_t e = hipEventRecord(other.fence, s->ctx->stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(other.stream, other.fence, 0);
-        if (e != hipSuccess) rc = fail(PTK_ERR_DEVICE, std::string("two-lane job: ") + hipGetErrorString(e));
+        // the other lanes' streams begin after what the context's stream holds so far (a film cleared or uploaded), and the
+        // context's stream goes on after the other lanes' work
+        hipError_t e = hipSuccess;
+        for (int l = 1; l < n_lanes && e == hipSuccess; l++) {
+            e = hipEventRecord(s->lanes[l].fence, s->ctx->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s->lanes[l].stream, s->lanes[l].fence, 0);
+        }
+        if (e != hipSuccess) rc = fail(PTK_ERR_DEVICE, std::string("job in several lanes: ") + hipGetErrorString(e));
         else {
-            if (!s->worker) s->worker.reset(new LaneWorker());
-            int other_rc = PTK_OK;
-            std::string other_message;
-            s->worker->start([&] {
-                try {
-                    other_rc = use(s->ctx);
-                    if (other_rc == PTK_OK) other_rc = run_lane(1);
-                }
-                catch (const std::exception& ex) {
-                    other_rc = fail(PTK_ERR_INVALID, std::string("unexpected error: ") + ex.what());
-                }
-                catch (...) {
-                    other_rc = fail(PTK_ERR_INVALID, "unexpected error");
-                }
-                if (other_rc != PTK_OK) other_message = g_error; // the message is the thread's own
-            });
+            int other_rc[MAX_LANES] = {};
+            std::string other_message[MAX_LANES];
+            for (int l = 1; l < n_lanes; l++) {
+                if (!s->workers[l - 1]) s->workers[l - 1].reset(new LaneWorker());
+                s->workers[l - 1]->start([&, l] {
+                    try {
+                        other_rc[l] = use(s->ctx);
+                        if (other_rc[l] == PTK_OK) other_rc[l] = run_lane(l);
+                    }
+                    catch (const std::exception& ex) {
+                        other_rc[l] = fail(PTK_ERR_INVALID, std::string("unexpected error: ") + ex.what());
+                    }
+                    catch (...) {
+                        other_rc[l] = fail(PTK_ERR_INVALID, "unexpected error");
+                    }
+                    if (other_rc[l] != PTK_OK) other_message[l] = g_error; // the message is the thread's own
+                });
+            }
             try {
                 rc = run_lane(0);
             }
-            catch (...) { // the worker is waited for whatever happens here: it works on this frame's variables
-                s->worker->wait();
+            catch (...) { // the workers are waited for whatever happens here: they work on this frame's variables
+                for (int l = 1; l < n_lanes; l++) s->workers[l - 1]->wait();
                 throw;
             }
-            s->worker->wait();
-            if (rc == PTK_OK && other_rc != PTK_OK) rc = fail(other_rc, other_message);
-            if (rc == PTK_OK) { // the context's stream goes on after the other lane's work
-                e = hipEventRecord(other.fence, other.stream);
-                if (e == hipSuccess) e = hipStreamWaitEvent(s->ctx->stream, other.fence, 0);
-                if (e != hipSuccess) rc = fail(PTK_ERR_DEVICE, std::string("two-lane job: ") + hipGetErrorString(e));
+            for (int l = 1; l < n_lanes; l++) s->workers[l - 1]->wait();
+            for (int l = 1; l < n_lanes; l++)
+                if (rc == PTK_OK && other_rc[l] != PTK_OK) rc = fail(other_rc[l], other_message[l]);
+            for (int l = 1; l < n_lanes && rc == PTK_OK; l++) { // the context's stream goes on after the other lanes' work
+                e = hipEventRecord(s->lanes[l].fence, s->lanes[l].stream);
+                if (e == hipSuccess) e = hipStreamWaitEvent(s->ctx->stream, s->lanes[l].fence, 0);
+                if (e != hipSuccess) rc = fail(PTK_ERR_DEVICE, std::string("job in several lanes: ") + hipGetErrorString(e));
             }
             // nothing of a failed job is left running on the caller's buffers
-            if (rc != PTK_OK) (void) hipStreamSynchronize(other.stream);
+            if (rc != PTK_OK)
+                for (int l = 1; l < n_lanes; l++) (void) hipStreamSynchronize(s->lanes[l].stream);
         }
     }
     // on every path out of the job: the lanes' statistics are added to the scene's and cleared
@@ -863,7 +871,7 @@ int ptk_set_option(const char* name, int64_t value) {
         return PTK_OK;
     }
     if (name && std::strcmp(name, "batch_lanes") == 0) {
-        if (value < 0 || value > 2) return fail(PTK_ERR_INVALID, "ptk_set_option: batch_lanes must be 0 (automatic), 1 or 2");
+        if (value < 0 || value > MAX_LANES) return fail(PTK_ERR_INVALID, "ptk_set_option: batch_lanes must be 0 (automatic) or 1 to 4");
         g_batch_lanes = static_cast<int>(value);
         return PTK_OK;
     }

@@ -74,9 +74,9 @@ def test_frame_is_the_same_however_it_is_cut(which, request):
         finally:
             pt.set_option("tail_records", 1 << 20)
         assert all(np.array_equal(a, b) for a, b in zip(whole, other)), tail_records
-    # one batch at a time or two (each on a stream and a host thread of its own), the host far ahead of the device's record
+    # one batch at a time, or two, three, four (each on a stream and a host thread of its own), the host far ahead of the device's record
     # counts or not at all: bit-identical
-    for option, value, default in (("batch_lanes", 1, 0), ("batch_lanes", 2, 0), ("launch_ahead", 0, 7)):
+    for option, value, default in (("batch_lanes", 1, 0), ("batch_lanes", 2, 0), ("batch_lanes", 3, 0), ("batch_lanes", 4, 0), ("launch_ahead", 0, 7)):
         pt.set_option(option, value)
         try:
             other, other_stats = render(hs, [pt.make_job(0, N, SPP, 0, 11)])

@@ -453,7 +453,7 @@ def test_record_staging_through_lds_delivers_every_record():
 
 
 def test_tuning_knobs_reject_what_they_do_not_know():
-    for name, value in (("batch_lanes", 3), ("batch_lanes", -1), ("launch_ahead", 8), ("launch_ahead", -1), ("tail_records", -1),
+    for name, value in (("batch_lanes", 5), ("batch_lanes", -1), ("launch_ahead", 8), ("launch_ahead", -1), ("tail_records", -1),
                         ("tail_records", (1 << 24) + 1), ("traverse_lanes", 2), ("gpu_bvh_build", 2), ("no_such_knob", 1)):
         with pytest.raises(RuntimeError):
             pt.set_option(name, value)
