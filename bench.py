@@ -48,7 +48,8 @@ HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak
 F64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (AMD's specification; half the 157.3 TFLOP/s fp32 vector rate)
 CLASS_NAMES = ["Diffuse", "Reflective", "Transparent", "Glossy", "MetallicMicrofacet", "ReflectiveMicrofacet",
                "TransparentMicrofacet", "MediumScatter"]
-PROFILE_EVERY = 4  # HIP events bracket the kernel families on every fourth timed step (event records drain the queue)
+PROFILE_EVERY = 8  # HIP events bracket the kernel families on every eighth timed step: event records drain the queue, and a
+                   # profiled step traces one batch at a time (a launch's time is its own only then), which costs it ~6 %
 
 
 def parse_args():

@@ -860,8 +860,9 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
     __shared__ double2 lds_record[STAGE ? N_PLANES * BLOCK : 1];
     double2* const wave_stage = lds_record + 64 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     __shared__ uint32_t wave_sums[BLOCK / 64][N_STATISTICS];
-    __shared__ uint32_t queue_counts[BLOCK / 64][2];
-    __shared__ uint32_t queue_base[2];
+    __shared__ uint32_t queue_counts[2][BLOCK / 64][2]; // two sets, used by alternate rounds
+    __shared__ uint32_t queue_base[2][2];
+    int queue_set = 0;
     PTK_TRAVERSAL_STACK(st, lds_stack, sc_global);
     __shared__ double lds_scene[CACHE ? LDS_SCENE_DOUBLES : 1];
     const DevScene sc = stage_scene<CACHE>(sc_global, lds_scene);
@@ -954,26 +955,28 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
                 if ((threadIdx.x & 63) >= static_cast<uint32_t>(off)) rays_before += up;
             }
             const int wave = threadIdx.x >> 6;
+            uint32_t (*counts)[2] = queue_counts[queue_set];
+            uint32_t* base = queue_base[queue_set];
             if ((threadIdx.x & 63) == 63) {
-                queue_counts[wave][0] = rays_before;
-                queue_counts[wave][1] = static_cast<uint32_t>(__popcll(vertex_mask));
+                counts[wave][0] = rays_before;
+                counts[wave][1] = static_cast<uint32_t>(__popcll(vertex_mask));
             }
             lds_barrier();
             if (threadIdx.x == 0) {
                 // both counters with one 64-bit atomic (rays in the low half, which never carries: a batch queues
                 // fewer than 2^32 rays): their one address serves about a hundred atomics per microsecond
                 unsigned long long total = 0;
-                for (int w = 0; w < BLOCK / 64; w++) total += queue_counts[w][0] + (static_cast<unsigned long long>(queue_counts[w][1]) << 32);
+                for (int w = 0; w < BLOCK / 64; w++) total += counts[w][0] + (static_cast<unsigned long long>(counts[w][1]) << 32);
                 const unsigned long long before = total ? atomicAdd(reinterpret_cast<unsigned long long*>(queues.counters), total) : 0ull;
-                queue_base[0] = static_cast<uint32_t>(before);
-                queue_base[1] = static_cast<uint32_t>(before >> 32);
+                base[0] = static_cast<uint32_t>(before);
+                base[1] = static_cast<uint32_t>(before >> 32);
             }
             lds_barrier();
             if (deferred) {
-                uint32_t ray_slot = queue_base[0] + rays_before - my_rays, vertex_slot = queue_base[1] + lanes_below(vertex_mask);
+                uint32_t ray_slot = base[0] + rays_before - my_rays, vertex_slot = base[1] + lanes_below(vertex_mask);
                 for (int w = 0; w < wave; w++) {
-                    ray_slot += queue_counts[w][0];
-                    vertex_slot += queue_counts[w][1];
+                    ray_slot += counts[w][0];
+                    vertex_slot += counts[w][1];
                 }
                 queues.vertices[vertex_slot] = dst;
 #pragma unroll
@@ -986,7 +989,9 @@ __global__ __launch_bounds__(BLOCK) PTK_WAVES_PER_SIMD(UV ? PTK_BOUNCE_UV_WAVES 
                     else queues.results[2 * dst + k] = RayResult{rays[k].limit, rays[k].obj, rays[k].prim}; // what the scan found
                 }
             }
-            lds_barrier(); // queue_counts and queue_base are rewritten next round
+            // No barrier here: the next round uses the other set, and a wave reaches the round after that only through
+            // the next round's two barriers, which every wave passes after its reads of this set.
+            queue_set ^= 1;
         }
         if (!DEFER) { // (a deferring kernel writes part of the chunk's records only: k_count_classes counts afterwards)
 #pragma unroll
