@@ -222,7 +222,7 @@ void* ptk_stream(void);
 /* Replaces Scene construction (src/scene.cpp:546-584) as seen by the render loop:
  * copies the description to the device, builds the mesh acceleration structure
  * (replaces BVH::Node::Node, src/bvh.cpp:129-165) and sizes the path pools.
- * `max_paths_in_flight` <= 0 selects the default (2^24); at most 2^26 is used: a job larger than a batch
+ * `max_paths_in_flight` <= 0 selects the default (2^25: two full batches); at most 2^26 is used: a job larger than a batch
  * (2^24 paths at most) is traced as batches of whole pixels, two or more at a time when it takes several (option
  * batch_lanes).  The caller may free every array of `desc` on return. */
 int ptk_scene_create(const PtkSceneDesc* desc, int64_t max_paths_in_flight, PtkScene** out);

@@ -242,7 +242,8 @@ struct DeviceBuffers {
 // Paths of one batch: the kernels address a record by a 32-bit byte offset into its pool (160 bytes per record).
 constexpr int64_t BATCH_MAX_PATHS = int64_t(1) << 24;
 static_assert(BATCH_MAX_PATHS * 160 <= (int64_t(1) << 32), "record offsets are 32-bit");
-constexpr int64_t DEFAULT_MAX_PATHS = BATCH_MAX_PATHS;  // paths in flight of a scene created without a limit of its own
+constexpr int64_t DEFAULT_MAX_PATHS = 2 * BATCH_MAX_PATHS; // paths in flight of a scene created without a limit of its own: two full batches
+                                                           // (buffers are sized by the batches a scene has really traced)
 constexpr int MAX_LANES = 4;                              // batches in flight at a time, at most
 constexpr int64_t MAX_PATHS_LIMIT = MAX_LANES * BATCH_MAX_PATHS; // a batch of the largest size in every lane
 constexpr int INFO_RING = 8;
