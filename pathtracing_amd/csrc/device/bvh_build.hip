@@ -227,13 +227,13 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_build_collapse(const CollapseIt
     const uint32_t i = blockIdx.x * BUILD_BLOCK + threadIdx.x;
     if (i >= n_in) return;
     const CollapseItem item = in[i];
-    int32_t kids[4];
+    int32_t kids[BVH_WIDTH];
     int nk = 2;
     kids[0] = t.left[item.binary];
     kids[1] = t.right[item.binary];
     auto is_leaf = [&](int32_t ref) { return ref < 0 || static_cast<int>(t.last[ref] - t.first[ref]) + 1 <= max_leaf; };
     auto box_of = [&](int32_t ref) { return ref >= 0 ? t.box[ref] : sorted_boxes[~ref]; };
-    while (nk < 4) { // open the inner child with the largest surface area
+    while (nk < BVH_WIDTH) { // open the inner child with the largest surface area
         int pick = -1;
         float area = -1.0f;
         for (int k = 0; k < nk; k++) {
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_build_collapse(const CollapseIt
         kids[nk++] = t.right[open];
     }
     BvhNode4 node;
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < BVH_WIDTH; k++) {
         node.child[k] = BVH_EMPTY;
         node.lo_x[k] = node.lo_y[k] = node.lo_z[k] = __builtin_inff();
         node.hi_x[k] = node.hi_y[k] = node.hi_z[k] = -__builtin_inff();
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(BUILD_BLOCK) void k_build_collapse(const CollapseIt
 // Entries the ordered walk's stack can hold inside the subtree of `node` (as Collapser::emit computes it for the host build).
 int stack_need(const std::vector<BvhNode4>& nodes, int32_t node) {
     int children = 0, below = 0;
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < BVH_WIDTH; c++) {
         const int32_t child = nodes[static_cast<size_t>(node)].child[c];
         if (child == BVH_EMPTY) continue;
         children++;

@@ -195,10 +195,10 @@ PTK_DEV int32_t visit_inner_children(const BvhNode4& n, const SlabRay& ray, doub
         r.py = Float2{py, py};
         r.pz = Float2{pz, pz};
     }
-    float tn[4];
-    int32_t ch[4];
+    float tn[BVH_WIDTH];
+    int32_t ch[BVH_WIDTH];
 #pragma unroll
-    for (int h = 0; h < 2; h++) { // children 2h and 2h + 1
+    for (int h = 0; h < BVH_WIDTH / 2; h++) { // children 2h and 2h + 1
         const Float2 lx = {n.lo_x[2 * h], n.lo_x[2 * h + 1]}, hx = {n.hi_x[2 * h], n.hi_x[2 * h + 1]};
         const Float2 ly = {n.lo_y[2 * h], n.lo_y[2 * h + 1]}, hy = {n.hi_y[2 * h], n.hi_y[2 * h + 1]};
         const Float2 lz = {n.lo_z[2 * h], n.lo_z[2 * h + 1]}, hz = {n.hi_z[2 * h], n.hi_z[2 * h + 1]};
@@ -220,14 +220,22 @@ PTK_DEV int32_t visit_inner_children(const BvhNode4& n, const SlabRay& ray, doub
             tn[c] = ok ? lo : FAR;
         }
     }
-    sort_pair(tn[0], ch[0], tn[1], ch[1]);
-    sort_pair(tn[2], ch[2], tn[3], ch[3]);
-    sort_pair(tn[0], ch[0], tn[2], ch[2]);
-    sort_pair(tn[1], ch[1], tn[3], ch[3]);
-    sort_pair(tn[1], ch[1], tn[2], ch[2]);
-    if (tn[3] < FAR) st.push(ch[3], tn[3]);
-    if (tn[2] < FAR) st.push(ch[2], tn[2]);
-    if (tn[1] < FAR) st.push(ch[1], tn[1]);
+    if (BVH_WIDTH == 4) {
+        sort_pair(tn[0], ch[0], tn[1], ch[1]);
+        sort_pair(tn[2], ch[2], tn[3], ch[3]);
+        sort_pair(tn[0], ch[0], tn[2], ch[2]);
+        sort_pair(tn[1], ch[1], tn[3], ch[3]);
+        sort_pair(tn[1], ch[1], tn[2], ch[2]);
+    }
+    else { // the 19-comparator network for eight
+        constexpr int NET[19][2] = {{0, 1}, {2, 3}, {4, 5}, {6, 7}, {0, 2}, {1, 3}, {4, 6}, {5, 7}, {1, 2}, {5, 6},
+                                    {0, 4}, {3, 7}, {1, 5}, {2, 6}, {1, 4}, {3, 6}, {2, 4}, {3, 5}, {3, 4}};
+#pragma unroll
+        for (int k = 0; k < 19; k++) sort_pair(tn[NET[k][0] % BVH_WIDTH], ch[NET[k][0] % BVH_WIDTH], tn[NET[k][1] % BVH_WIDTH], ch[NET[k][1] % BVH_WIDTH]);
+    }
+#pragma unroll
+    for (int c = BVH_WIDTH - 1; c >= 1; c--)
+        if (tn[c] < FAR) st.push(ch[c], tn[c]);
     pop = !(tn[0] < FAR);
     return ch[0];
 }
@@ -249,15 +257,16 @@ PTK_DEV WalkStep walk_step(const DevScene& sc, int32_t& node, int& tri_i, int64_
     const uint32_t code = static_cast<uint32_t>(~node);
     const int64_t tri = first_tri + (code >> 3) + tri_i;
     const double* src = is_inner ? reinterpret_cast<const double*>(sc.nodes + node) : reinterpret_cast<const double*>(sc.tri_hot + tri);
-    double raw[14];
+    constexpr int NODE_LOADS = BVH_NODE_BYTES / 16;
+    double raw[2 * NODE_LOADS];
 #pragma unroll
     for (int k = 0; k < 5; k++) __builtin_memcpy(raw + 2 * k, src + 2 * k, 16);
     bool pop = false; // the lane's next node comes from its stack
     if (is_inner) {
 #pragma unroll
-        for (int k = 5; k < 7; k++) __builtin_memcpy(raw + 2 * k, src + 2 * k, 16);
+        for (int k = 5; k < NODE_LOADS; k++) __builtin_memcpy(raw + 2 * k, src + 2 * k, 16);
         BvhNode4 nd;
-        __builtin_memcpy(&nd, raw, 112);
+        __builtin_memcpy(&nd, raw, BVH_NODE_BYTES);
         node = visit_inner_children<NARROW>(nd, slab, t_best, st, pop);
     }
     else {

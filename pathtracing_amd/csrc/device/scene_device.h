@@ -133,12 +133,19 @@ struct TriCold { // Triangle's derived members (include/objects.h:114-138)
     int32_t face_index; // index of the triangle in OBJ face order within its mesh
 };
 
-struct BvhNode4 { // 128 bytes
-    float lo_x[4], lo_y[4], lo_z[4];
-    float hi_x[4], hi_y[4], hi_z[4];
-    int32_t child[4]; // >= 0 inner node; < 0 leaf: ~child = first_tri_local * 8 + (count - 1); EMPTY for none
-    int32_t _pad[4];
+// Children per node: 4; 8 in measurement builds (-DPTK_BVH_WIDTH=8: host build and one-lane walk only).
+#ifndef PTK_BVH_WIDTH
+#define PTK_BVH_WIDTH 4
+#endif
+constexpr int BVH_WIDTH = PTK_BVH_WIDTH;
+static_assert(BVH_WIDTH == 4 || BVH_WIDTH == 8, "nodes of four or eight children");
+struct BvhNode4 { // 128 bytes (256 with eight children)
+    float lo_x[BVH_WIDTH], lo_y[BVH_WIDTH], lo_z[BVH_WIDTH];
+    float hi_x[BVH_WIDTH], hi_y[BVH_WIDTH], hi_z[BVH_WIDTH];
+    int32_t child[BVH_WIDTH]; // >= 0 inner node; < 0 leaf: ~child = first_tri_local * 8 + (count - 1); EMPTY for none
+    int32_t _pad[BVH_WIDTH];
 };
+constexpr int BVH_NODE_BYTES = 28 * BVH_WIDTH; // boxes and children, without the padding
 constexpr int32_t BVH_EMPTY = INT32_MIN;
 // The same node for k_traverse, which walks a hierarchy with four lanes per ray, one lane per child: child c's box
 // and reference are 32 consecutive bytes (two 16-byte loads per lane; the four lanes of a ray read the four quarters

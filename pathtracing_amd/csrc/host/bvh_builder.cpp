@@ -162,14 +162,14 @@ struct Collapser {
         max_depth = std::max(max_depth, depth);
         const int32_t me = static_cast<int32_t>(out.size());
         out.emplace_back();
-        int32_t kids[4];
-        int level[4]; // binary levels below `id`
+        int32_t kids[BVH_WIDTH];
+        int level[BVH_WIDTH]; // binary levels below `id`
         int nk = 0;
         kids[nk] = n2[static_cast<size_t>(id)].left;
         level[nk++] = 1;
         kids[nk] = n2[static_cast<size_t>(id)].right;
         level[nk++] = 1;
-        while (nk < 4) { // open the inner child with the largest surface area (level_order: the shallowest first)
+        while (nk < BVH_WIDTH) { // open the inner child with the largest surface area (level_order: the shallowest first)
             int pick = -1;
             double area = -1;
             for (int i = 0; i < nk; i++) {
@@ -190,7 +190,7 @@ struct Collapser {
             level[nk++] = level[pick];
         }
         BvhNode4 node{};
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < BVH_WIDTH; i++) {
             node.child[i] = BVH_EMPTY;
             node.lo_x[i] = node.lo_y[i] = node.lo_z[i] = std::numeric_limits<float>::infinity();
             node.hi_x[i] = node.hi_y[i] = node.hi_z[i] = -std::numeric_limits<float>::infinity();
@@ -227,7 +227,7 @@ static void build_wide(const std::vector<Node2>& nodes, int32_t root, bool level
     if (nodes[static_cast<size_t>(root)].left < 0) { // the whole mesh fits one leaf: root with a single leaf child
         BvhNode4 node{};
         const Node2& c = nodes[static_cast<size_t>(root)];
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < BVH_WIDTH; i++) {
             node.child[i] = BVH_EMPTY;
             node.lo_x[i] = node.lo_y[i] = node.lo_z[i] = std::numeric_limits<float>::infinity();
             node.hi_x[i] = node.hi_y[i] = node.hi_z[i] = -std::numeric_limits<float>::infinity();

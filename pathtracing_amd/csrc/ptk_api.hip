@@ -415,7 +415,7 @@ constexpr uint64_t BIN_BYTES_PER_VERTEX = 4;                        // list entr
 constexpr uint64_t GENERATE_BYTES_PER_PATH = RECORD_BYTES + 1;          // record, class out
 constexpr uint64_t ACCUMULATE_BYTES_PER_PATH = 32 + 3 * 16;         // results in
 constexpr uint64_t TRAVERSE_BYTES_PER_RAY = sizeof(RayRequest) + sizeof(RayResult);
-constexpr uint64_t NODE_BYTES = sizeof(BvhNode4) - 16; // without the padding
+constexpr uint64_t NODE_BYTES = BVH_NODE_BYTES; // without the padding
 // two sets of statistics slots (k_bounce and k_bounce_resume; k_traverse), then their totals
 constexpr size_t STATISTICS_SET = static_cast<size_t>(N_STATISTICS) * STATISTICS_SLOTS;
 constexpr size_t STATISTICS_VALUES = 2 * (STATISTICS_SET + N_STATISTICS);
@@ -893,6 +893,7 @@ int ptk_set_option(const char* name, int64_t value) {
     }
     if (name && std::strcmp(name, "traverse_lanes") == 0) {
         if (value != 1 && value != 4) return fail(PTK_ERR_INVALID, "ptk_set_option: traverse_lanes must be 1 or 4");
+        if (value == 4 && BVH_WIDTH != 4) return fail(PTK_ERR_INVALID, "ptk_set_option: four lanes per ray need nodes of four children");
         g_quad_traverse = value == 4;
         return PTK_OK;
     }
@@ -1152,7 +1153,7 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
                 o.bvh_root = static_cast<int32_t>(nodes.size());
                 const int32_t node_base = static_cast<int32_t>(nodes.size());
                 for (BvhNode4 node : bvh.nodes) {
-                    for (int c = 0; c < 4; c++)
+                    for (int c = 0; c < BVH_WIDTH; c++)
                         if (node.child[c] >= 0) node.child[c] += node_base;
                     nodes.push_back(node);
                 }
@@ -1262,7 +1263,7 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
         else if (o.type == PTK_OBJ_MESH && o.bvh_root >= 0) { // bounds of the whole mesh = union of the root's children
             const BvhNode4& root = nodes[static_cast<size_t>(o.bvh_root)];
             double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-            for (int c = 0; c < 4; c++) {
+            for (int c = 0; c < BVH_WIDTH; c++) {
                 if (root.child[c] == BVH_EMPTY) continue;
                 lo[0] = std::min(lo[0], static_cast<double>(root.lo_x[c]));
                 lo[1] = std::min(lo[1], static_cast<double>(root.lo_y[c]));
@@ -1417,7 +1418,7 @@ int ptk_scene_create(const PtkSceneDesc* d, int64_t max_paths_in_flight, PtkScen
     HIP_TRY(buf.upload(&dev.nodes, nodes));
     {
         std::vector<BvhNodeQuad> quads(nodes.size()); // the same nodes in the layout of k_traverse_quad
-        for (size_t i = 0; i < nodes.size(); i++)
+        for (size_t i = 0; i < nodes.size() && BVH_WIDTH == 4; i++) // (the walk with four lanes per ray knows nodes of four only)
             for (int c = 0; c < 4; c++) {
                 BvhChildBox& box = quads[i].c[c];
                 box.lo[0] = nodes[i].lo_x[c];

@@ -29,7 +29,7 @@ static bool walk(const BuiltBvh& b, const double* v, int32_t node, int depth, Bo
     depth_of[static_cast<size_t>(node)] = depth;
     const BvhNode4& n = b.nodes[static_cast<size_t>(node)];
     int children = 0, below = 0;
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < BVH_WIDTH; c++) {
         if (n.child[c] == BVH_EMPTY) continue;
         children++;
         Box3 sub;

@@ -8,7 +8,8 @@ tmp=$(mktemp -d)
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -Idevice -I. $*"
 SOURCES="device/kernels.hip device/denoise.hip device/bvh_build.hip ptk_api.hip $(ls device/variants/*.hip)"
 printf '%s\n' $SOURCES | xargs -P 8 -I{} sh -c "hipcc $F -c {} -o $tmp/\$(basename {} .hip).o"
-g++ -std=c++17 -O3 -fPIC -I../../include -I. -c host/bvh_builder.cpp -o $tmp/bvh_builder.o
+DEFINES=$(printf '%s\n' "$@" | grep '^-D' | tr '\n' ' ') # the host-side hierarchy builder sees the same macros
+g++ -std=c++17 -O3 -fPIC $DEFINES -I../../include -I. -c host/bvh_builder.cpp -o $tmp/bvh_builder.o
 hipcc --offload-arch=gfx950 -shared -fPIC $tmp/*.o -o ../libptk_$name.so -lpthread
 rm -rf $tmp
 echo built pathtracing_amd/libptk_$name.so
