@@ -376,6 +376,7 @@ struct PtkScene {
 namespace {
 
 int ensure_capacity(const PtkScene* s, BatchLane& lane, int64_t paths) {
+    if (paths > BATCH_MAX_PATHS) return fail(PTK_ERR_MEMORY, "a batch of more paths than record offsets can address"); // (for_each_batch never asks)
     if (paths <= lane.capacity) return PTK_OK;
     lane.buffers.free_all(); // the previous, smaller arrays
     lane.capacity = 0;
