@@ -382,7 +382,10 @@ def run_workload(pt, args, ds, workload, width, height, spp, steps, warmup, code
     record = {
         "value": value, "unit": "Mpaths/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
         "config": {"workload": f"{workload_name}, {W}x{H}, {spp} spp per step ({spp * steps} spp in the timed region)",
-                   "paths_per_step_per_gpu": own_pixels * spp, "partition": partition, "scene_build_s": build_s},
+                   "paths_per_step_per_gpu": own_pixels * spp,
+                   "paths_in_flight_limit_per_gpu": max(min(width * height * spp, lanes << 24), 1 << 22),
+                   "batching": "a step is traced as batches of whole pixels, at most 2^24 paths each, two at a time",
+                   "partition": partition, "scene_build_s": build_s},
         "rays": {"Grays_per_s": (st.extension_rays + st.shadow_rays) * world / elapsed / 1e9,
                  "extension_rays_per_path": st.extension_rays / max(st.paths, 1),
                  "shadow_rays_per_path": st.shadow_rays / max(st.paths, 1),
