@@ -59,6 +59,7 @@ struct Builder {
             nodes[static_cast<size_t>(id)].count = count;
             return id;
         }
+        // the axis of the median split (and of the surface-area search when only one axis is searched): the longest
         int axis = 0;
         double extent = cbox.hi[0] - cbox.lo[0];
         for (int a = 1; a < 3; a++) {
@@ -70,43 +71,53 @@ struct Builder {
         uint32_t mid = first + count / 2;
         bool split_done = false;
         if (extent > 0 && depth < sah_depth_cap) {
+            // Binned surface-area heuristic over all three axes in one pass over the triangles: the cheapest of the
+            // 3 * (n_bins - 1) candidate planes (cost = area * count of either side).
             const int B = n_bins;
-            std::vector<Box> bin_box(static_cast<size_t>(B));
-            std::vector<uint32_t> bin_count(static_cast<size_t>(B), 0);
-            const double scale = B / extent;
-            auto bin_of = [&](uint32_t tri) {
-                int b = static_cast<int>((centroids[3 * static_cast<size_t>(tri) + axis] - cbox.lo[axis]) * scale);
+            std::vector<Box> bin_box(static_cast<size_t>(3 * B));
+            std::vector<uint32_t> bin_count(static_cast<size_t>(3 * B), 0);
+            double scale[3];
+            for (int a = 0; a < 3; a++) scale[a] = cbox.hi[a] > cbox.lo[a] ? B / (cbox.hi[a] - cbox.lo[a]) : 0.0;
+            auto bin_of = [&](uint32_t tri, int a) {
+                int b = static_cast<int>((centroids[3 * static_cast<size_t>(tri) + a] - cbox.lo[a]) * scale[a]);
                 return std::min(std::max(b, 0), B - 1);
             };
             for (uint32_t i = first; i < first + count; i++) {
-                int b = bin_of(index[i]);
-                bin_box[static_cast<size_t>(b)].grow(boxes[index[i]]);
-                bin_count[static_cast<size_t>(b)]++;
+                const uint32_t tri = index[i];
+                for (int a = 0; a < 3; a++) {
+                    const size_t slot = static_cast<size_t>(a * B + bin_of(tri, a));
+                    bin_box[slot].grow(boxes[tri]);
+                    bin_count[slot]++;
+                }
             }
-            std::vector<double> right_area(static_cast<size_t>(B), 0.0);
-            Box acc;
-            for (int b = B - 1; b > 0; b--) {
-                if (bin_count[static_cast<size_t>(b)]) acc.grow(bin_box[static_cast<size_t>(b)]);
-                right_area[static_cast<size_t>(b)] = acc.half_area();
-            }
-            Box lacc;
-            uint32_t lcount = 0;
             double best = std::numeric_limits<double>::infinity();
-            int best_bin = -1;
-            for (int b = 0; b < B - 1; b++) {
-                if (bin_count[static_cast<size_t>(b)]) lacc.grow(bin_box[static_cast<size_t>(b)]);
-                lcount += bin_count[static_cast<size_t>(b)];
-                uint32_t rcount = count - lcount;
-                if (lcount == 0 || rcount == 0) continue;
-                double cost = lacc.half_area() * lcount + right_area[static_cast<size_t>(b) + 1] * rcount;
-                if (cost < best) {
-                    best = cost;
-                    best_bin = b;
+            int best_bin = -1, best_axis = axis;
+            std::vector<double> right_area(static_cast<size_t>(B), 0.0);
+            for (int a = 0; a < 3; a++) {
+                if (scale[a] == 0.0) continue;
+                Box acc;
+                for (int b = B - 1; b > 0; b--) {
+                    if (bin_count[static_cast<size_t>(a * B + b)]) acc.grow(bin_box[static_cast<size_t>(a * B + b)]);
+                    right_area[static_cast<size_t>(b)] = acc.half_area();
+                }
+                Box lacc;
+                uint32_t lcount = 0;
+                for (int b = 0; b < B - 1; b++) {
+                    if (bin_count[static_cast<size_t>(a * B + b)]) lacc.grow(bin_box[static_cast<size_t>(a * B + b)]);
+                    lcount += bin_count[static_cast<size_t>(a * B + b)];
+                    const uint32_t rcount = count - lcount;
+                    if (lcount == 0 || rcount == 0) continue;
+                    const double cost = lacc.half_area() * lcount + right_area[static_cast<size_t>(b) + 1] * rcount;
+                    if (cost < best) {
+                        best = cost;
+                        best_bin = b;
+                        best_axis = a;
+                    }
                 }
             }
             if (best_bin >= 0) {
                 auto it = std::partition(index.begin() + first, index.begin() + first + count,
-                                         [&](uint32_t tri) { return bin_of(tri) <= best_bin; });
+                                         [&](uint32_t tri) { return bin_of(tri, best_axis) <= best_bin; });
                 mid = static_cast<uint32_t>(it - index.begin());
                 split_done = mid > first && mid < first + count;
             }
