@@ -309,7 +309,10 @@ struct BatchParams {
 // counts, k_bin_scan turns them into offsets (and this summary), k_bin_scatter writes the
 // class-sorted index list.  BIN_CHUNK consecutive records belong to one block in all three.
 constexpr int BIN_BLOCK = 256;
-constexpr int BIN_ROUNDS = 4;
+#ifndef PTK_BIN_ROUNDS
+#define PTK_BIN_ROUNDS 4
+#endif
+constexpr int BIN_ROUNDS = PTK_BIN_ROUNDS;
 constexpr int BIN_CHUNK = BIN_BLOCK * BIN_ROUNDS;
 struct BinInfo {
     uint32_t start[N_CLASSES]; // first entry of each class segment in the sorted list
