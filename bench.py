@@ -232,7 +232,7 @@ def run_workload(pt, args, ds, workload, width, height, spp, steps, warmup, code
     band_start, own_pixels, band_pixels, band_stride = band_job(rank, world, W, H, band_rows=8) if tiles else (0, n_pixels, 0, 0)
     # a step of more than 2^24 paths is traced as batches of whole pixels, several at a time (option batch_lanes), each of
     # at most 2^24 paths
-    paths_in_flight = max(min(width * height * spp, max(int(dict(o.split("=", 1) for o in args.option).get("batch_lanes", 0)), 2) << 24), 1 << 22)
+    paths_in_flight = max(min(width * height * spp, max(int(dict(o.split("=", 1) for o in args.option).get("batch_lanes", 0)), 3) << 24), 1 << 22)
     scene = pt.DeviceScene(host_scene, max_paths_in_flight=paths_in_flight)
     build_s = time.perf_counter() - t_build
 
@@ -392,7 +392,7 @@ def run_workload(pt, args, ds, workload, width, height, spp, steps, warmup, code
         "config": {"workload": f"{workload_name}, {W}x{H}, {spp} spp per step ({spp * steps} spp in the timed region)",
                    "paths_per_step_per_gpu": own_pixels * spp,
                    "paths_in_flight_limit_per_gpu": paths_in_flight,
-                   "batching": "a step is traced as batches of whole pixels, at most 2^24 paths each, two at a time",
+                   "batching": "a step is traced as batches of whole pixels, at most 2^24 paths each, two at a time (three in scenes with meshes)",
                    "partition": partition, "scene_build_s": build_s},
         "rays": {"Grays_per_s": (st.extension_rays + st.shadow_rays) * world / elapsed / 1e9,
                  "extension_rays_per_path": st.extension_rays / max(st.paths, 1),

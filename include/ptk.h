@@ -222,7 +222,7 @@ void* ptk_stream(void);
 /* Replaces Scene construction (src/scene.cpp:546-584) as seen by the render loop:
  * copies the description to the device, builds the mesh acceleration structure
  * (replaces BVH::Node::Node, src/bvh.cpp:129-165) and sizes the path pools.
- * `max_paths_in_flight` <= 0 selects the default (2^25: two full batches); at most 2^26 is used: a job larger than a batch
+ * `max_paths_in_flight` <= 0 selects the default (3 x 2^24: three full batches); at most 2^26 is used: a job larger than a batch
  * (2^24 paths at most) is traced as batches of whole pixels, two or more at a time when it takes several (option
  * batch_lanes).  The caller may free every array of `desc` on return. */
 int ptk_scene_create(const PtkSceneDesc* desc, int64_t max_paths_in_flight, PtkScene** out);
@@ -325,7 +325,7 @@ int ptk_set_profiling(int enabled);
  *   "batch_lanes": 1 traces the batches of a job one after the other; n = 2 to 4 cuts jobs of 2^21 paths or more into
  *     batches of 1/n of the paths-in-flight limit (2^24 paths at most) and traces n at a time, each on a stream and a
  *     host thread of its own; 0 (default) traces two at a time in scenes with meshes and wherever a job takes more
- *     than one batch anyway.
+ *     than one batch anyway, three in scenes with meshes when a job takes more than two.
  *   "gpu_bvh_build": 1 builds the hierarchy of every mesh of 1024 triangles or more on the GPU when the next scenes
  *     are created (a linear BVH over Morton-ordered triangles: built in milliseconds, costlier to walk than the
  *     host's surface-area tree); 0 (default) builds on the host.  A mesh whose build the device has no memory for
