@@ -48,8 +48,9 @@ HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak
 F64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (AMD's specification; half the 157.3 TFLOP/s fp32 vector rate)
 CLASS_NAMES = ["Diffuse", "Reflective", "Transparent", "Glossy", "MetallicMicrofacet", "ReflectiveMicrofacet",
                "TransparentMicrofacet", "MediumScatter"]
-PROFILE_EVERY = 8  # HIP events bracket the kernel families on every eighth timed step: event records drain the queue, and a
-                   # profiled step traces one batch at a time (a launch's time is its own only then), which costs it ~6 %
+PROFILE_EVERY = 16  # HIP events bracket the kernel families on every sixteenth timed step (the first one, in a default run): event
+                    # records drain the queue, and a profiled step traces one batch at a time (a launch's time is its own
+                    # only then), which makes it 6 % slower on the example and 16 % slower on the mesh (three batches in flight)
 
 
 def parse_args():
@@ -64,7 +65,7 @@ def parse_args():
     ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--mesh-lon", type=int, default=1024)
     ap.add_argument("--mesh-lat", type=int, default=513)
-    ap.add_argument("--mesh-steps", type=int, default=8, help="timed steps of the mesh sub-record")
+    ap.add_argument("--mesh-steps", type=int, default=16, help="timed steps of the mesh sub-record")
     ap.add_argument("--only-headline", action="store_true", help="skip the mesh and denoise sub-records")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)

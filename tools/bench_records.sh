@@ -10,7 +10,7 @@ mkdir -p "$out"
 cd "$R"
 timeout -k 10 400 python bench.py > "$out/default.json"
 for w in mesh room cloud; do
-  timeout -k 10 200 python bench.py --only-headline --no-cpu-baseline --workload $w --steps 8 > "$out/$w.json"
+  timeout -k 10 200 python bench.py --only-headline --no-cpu-baseline --workload $w --steps 16 > "$out/$w.json"
 done
 python - "$out" <<'PY'
 import json, sys, os
