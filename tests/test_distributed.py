@@ -86,12 +86,13 @@ def _worker(rank, world, port, scene_dir, mode, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["samples", "rows"])
-def test_two_ranks_reproduce_the_single_process_image(tmp_path, mode):
+@pytest.mark.parametrize("mode,world,height", [("samples", 2, 24), ("rows", 2, 24), ("samples", 3, 20), ("rows", 3, 20)])
+def test_ranks_reproduce_the_single_process_image(tmp_path, mode, world, height):
+    """Two ranks on a frame of three whole bands, three ranks on a frame whose last band is half a band (20 rows)."""
     from oracle import binding as ob
-    d = scenes.cornell_example(str(tmp_path / "ex"), WIDTH=32, HEIGHT=24)
-    port = 29500 + (os.getpid() % 2000) + (0 if mode == "samples" else 1)
-    mp.spawn(_worker, args=(2, port, d, mode, str(tmp_path)), nprocs=2, join=True)
+    d = scenes.cornell_example(str(tmp_path / "ex"), WIDTH=32, HEIGHT=height)
+    port = 29500 + (os.getpid() % 2000) + (0 if mode == "samples" else 1) + 2 * world
+    mp.spawn(_worker, args=(world, port, d, mode, str(tmp_path)), nprocs=world, join=True)
     got = np.load(str(tmp_path / f"{mode}.npz"))
     hs = pt.load_scene_directory(d)
     W, H = hs.settings.width, hs.settings.height
@@ -113,7 +114,9 @@ def test_two_ranks_reproduce_the_single_process_image(tmp_path, mode):
         else:
             np.testing.assert_allclose(got[name], want.reshape(-1), rtol=1e-12, atol=1e-15)
     n = W * H
-    if mode == "rows":  # a rank sends its own bands only: half of the frame (3 bands of 8 rows, padded to 4), films and counters
-        assert got["wire"][0] == (9 * 8 + 8) * (32 * 32) // 2
+    if mode == "rows":  # a rank sends its own bands only (the frame padded to whole rounds of one band per rank), films and counters
+        band_pixels = 8 * W
+        rounds = -(-n // (band_pixels * world))
+        assert got["wire"][0] == (9 * 8 + 8) * rounds * band_pixels
     else:
         assert got["wire"][0] == 10 * 8 * n
